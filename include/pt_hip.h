@@ -1,0 +1,144 @@
+/* pt_hip.h — C ABI of libpt_hip.so, the MI355X (gfx950) path-tracing kernels.
+ *
+ * The reference has no FFI: its hot path is header-inline __device__ C++ called
+ * from one __global__ kernel (main.cu:6-8,65).  This ABI is the boundary a host
+ * program binds instead of launching that kernel: plain pointers and sizes, no
+ * C++ types.  Every entry point returns 0 on success or a non-zero HIP/PT status
+ * and never exits the process; pt_last_error() gives the text in the reference's
+ * check_cuda shape (main.cu:11-19): "HIP error = <n> at <file>:<line> '<expr>'".
+ *
+ * Pointers named d_* are DEVICE pointers on the scene's device; everything else
+ * is host memory.  Calls are stream-ordered on `stream` (a hipStream_t passed as
+ * void*, NULL = the default stream) and do not synchronise the device.
+ */
+#ifndef PT_HIP_H
+#define PT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Shape tags (class hierarchy of shapes.h:103,137,225,323). */
+enum { PT_PLANE = 0, PT_CUBE = 1, PT_CYLINDER = 2, PT_SPHERE = 3 };
+
+/* Material, field for field (materials.h:12-38); 72 bytes like the reference's. */
+typedef struct pt_material {
+    float albedo[3];
+    float emissive[3];
+    float f0;
+    float specularRoughness;
+    float specularColor[3];
+    float IOR;
+    float transparency;
+    float refractionRoughness;
+    float refractionColor[3];
+    int32_t bsdfType;
+} pt_material;
+
+/* One Shape as its constructor arguments (shapes.h:111,147,229,325):
+ * transform = rows of the affine [L | t] (Eigen::Affine3f without its last row),
+ * bounds = Plane xMin,yMin,xMax,yMax (ignored by the other types). */
+typedef struct pt_prim {
+    int32_t type;
+    int32_t material;
+    float transform[12];
+    float bounds[4];
+} pt_prim;
+
+/* Math mode of pt_render. */
+enum {
+    PT_MATH_PARITY = 0, /* reference operation order, IEEE div/sqrt, no FMA contraction */
+    PT_MATH_FAST = 1    /* same algorithm, FMA + v_rcp/v_rsq/v_sin/v_cos, restructured tests */
+};
+/* Framebuffer layout of pt_render. */
+enum {
+    PT_FB_AOS = 0, /* fb[(j*max_x+i)*3 + c]  — the reference's vec3* fb (main.cu:68) */
+    PT_FB_SOA = 1  /* fb[c*max_x*max_y + j*max_x + i] — three planes */
+};
+
+/* config_t (main.cu:22-28) followed by the values the reference hard-codes:
+ * n_samples (main.cu:54), n_bounces (bsdf.h:75), the RNG seed (main.cu:60 seeds
+ * by pixel index only; seed selects an independent family of streams), and the
+ * row tile [row_begin,row_end) this call renders (row 0 = bottom of the image,
+ * main.cu:38). */
+typedef struct pt_config {
+    float camera_pos[3];
+    int32_t max_x;
+    int32_t max_y;
+    float focal_length;
+    float view_port_height;
+    int32_t n_samples;
+    int32_t n_bounces;
+    uint32_t seed;
+    int32_t row_begin;
+    int32_t row_end;
+    int32_t fb_layout;
+    int32_t math_mode;
+} pt_config;
+
+typedef struct pt_scene pt_scene; /* opaque; owns the device copy of the primitive table */
+
+/* Replaces cudaMalloc + constructScene<<<1,1>>> (main.cu:213-220): flattens the
+ * shapes into the device primitive table on `device`. */
+int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, int n_mats, int device, pt_scene** out);
+int pt_scene_free(pt_scene* scene);
+int pt_scene_device(const pt_scene* scene);
+
+/* The reference's default scene as data (main.cu:73-195): writes 11 primitives
+ * and 8 materials; returns the primitive count. */
+int pt_default_scene(pt_prim* prims, pt_material* mats, int* n_mats);
+/* Stress scene: the default box, light and cube plus an n x n grid of glass
+ * spheres (material of main.cu:150-157).  Returns the primitive count
+ * (8 + n*n); prims/mats must hold that many / 8 entries. */
+int pt_glass_grid_scene(int n, pt_prim* prims, pt_material* mats, int* n_mats);
+/* Synthetic scene: the whole default scene (11 primitives) plus n_spheres spheres
+ * and n_cubes cubes placed by the counter RNG with `seed`.  Returns the
+ * primitive count (11 + n_spheres + n_cubes). */
+int pt_synthetic_scene(int n_spheres, int n_cubes, uint32_t seed, pt_prim* prims, pt_material* mats, int* n_mats);
+
+/* Host-side focal length exactly as main.cu:229-232 computes it (integer nx/ny). */
+float pt_focal_length(int nx, int ny, float v_height, float fov_deg);
+
+/* Replaces the render<<<blocks,threads>>> launch (main.cu:236).  d_fb is the
+ * FULL max_x*max_y*3 float framebuffer in device memory; only pixels of rows
+ * [row_begin,row_end) are written. */
+int pt_render(const pt_scene* scene, const pt_config* cfg, float* d_fb, void* stream);
+
+/* Shape::getIntersections (filter != 0; shapes.h:60-75) or Shape::getRayPath
+ * (filter == 0, rays taken as already local; shapes.h:58) of primitive `prim`
+ * for n_rays rays.  d_o, d_d: [n_rays][3].  Outputs (all device, any may be
+ * NULL): d_n[n_rays] = n_intersections; for first (1) and second (2):
+ * d_hit, d_t [n_rays]; d_pos, d_nrm [n_rays][3]. */
+int pt_raypath_batch(const pt_scene* scene, int prim, const float* d_o, const float* d_d, int n_rays, int filter,
+                     int32_t* d_n, int32_t* d_hit1, float* d_t1, float* d_pos1, float* d_nrm1,
+                     int32_t* d_hit2, float* d_t2, float* d_pos2, float* d_nrm2, void* stream);
+
+/* getNearestIntersection (shapes.h:79-100) for n_rays rays: winning primitive
+ * index (-1 = miss), distance, world position, facing normal, inside flag. */
+int pt_nearest_batch(const pt_scene* scene, const float* d_o, const float* d_d, int n_rays,
+                     int32_t* d_prim, float* d_t, float* d_pos, float* d_nrm, int32_t* d_inside, void* stream);
+
+/* tracePath (bsdf.h:73-168) for n_rays explicit rays; ray i draws from the
+ * stream (seed, d_pixel[i], d_sample[i]) starting at slot 2.  d_rgb: [n_rays][3]. */
+int pt_trace_paths(const pt_scene* scene, const float* d_o, const float* d_d, const uint32_t* d_pixel,
+                   const uint32_t* d_sample, int n_rays, uint32_t seed, int n_bounces, int math_mode,
+                   float* d_rgb, void* stream);
+
+/* Raw draws of the counter RNG: bits and (0,1] uniforms of slots [0,n_slots) of
+ * stream (seed, pixel, sample), computed on the device. */
+int pt_rng_draws(int device, uint32_t seed, uint32_t pixel, uint32_t sample, int n_slots,
+                 uint32_t* d_bits, float* d_uniforms, void* stream);
+
+/* PPM P3 text of a host AoS framebuffer exactly as main.cu:240-253 prints it.
+ * Returns the byte count, or -1 if cap is too small. */
+long pt_ppm_p3(const float* fb, int nx, int ny, char* out, long cap);
+
+const char* pt_last_error(void);
+const char* pt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_HIP_H */

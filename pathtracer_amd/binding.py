@@ -1,0 +1,236 @@
+"""ctypes binding of libpt_hip.so (include/pt_hip.h).
+
+The library is the product; this module only marshals arguments.  Device memory
+is held in torch tensors (torch is used for allocation, streams and
+torch.distributed, nothing else) and passed to the C ABI as raw device pointers.
+There is no CPU fallback: if the shared library is missing, importing fails.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpt_hip.so")
+
+PT_PLANE, PT_CUBE, PT_CYLINDER, PT_SPHERE = 0, 1, 2, 3
+PT_MATH_PARITY, PT_MATH_FAST = 0, 1
+PT_FB_AOS, PT_FB_SOA = 0, 1
+
+
+class pt_material(C.Structure):
+    _fields_ = [
+        ("albedo", C.c_float * 3), ("emissive", C.c_float * 3), ("f0", C.c_float),
+        ("specularRoughness", C.c_float), ("specularColor", C.c_float * 3), ("IOR", C.c_float),
+        ("transparency", C.c_float), ("refractionRoughness", C.c_float),
+        ("refractionColor", C.c_float * 3), ("bsdfType", C.c_int32),
+    ]
+
+
+class pt_prim(C.Structure):
+    _fields_ = [("type", C.c_int32), ("material", C.c_int32), ("transform", C.c_float * 12), ("bounds", C.c_float * 4)]
+
+
+class pt_config(C.Structure):
+    _fields_ = [
+        ("camera_pos", C.c_float * 3), ("max_x", C.c_int32), ("max_y", C.c_int32),
+        ("focal_length", C.c_float), ("view_port_height", C.c_float),
+        ("n_samples", C.c_int32), ("n_bounces", C.c_int32), ("seed", C.c_uint32),
+        ("row_begin", C.c_int32), ("row_end", C.c_int32), ("fb_layout", C.c_int32), ("math_mode", C.c_int32),
+    ]
+
+
+class PtError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "pathtracer_amd: %s is missing; build it with `make -C pathtracer_amd/csrc` "
+            "(or __graft_entry__.build()). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u32, f32 = C.c_void_p, C.c_int, C.c_uint32, C.c_float
+    L.pt_last_error.restype = C.c_char_p
+    L.pt_version.restype = C.c_char_p
+    L.pt_focal_length.restype = f32
+    L.pt_focal_length.argtypes = [i32, i32, f32, f32]
+    L.pt_default_scene.argtypes = [C.POINTER(pt_prim), C.POINTER(pt_material), C.POINTER(i32)]
+    L.pt_glass_grid_scene.argtypes = [i32, C.POINTER(pt_prim), C.POINTER(pt_material), C.POINTER(i32)]
+    L.pt_synthetic_scene.argtypes = [i32, i32, u32, C.POINTER(pt_prim), C.POINTER(pt_material), C.POINTER(i32)]
+    L.pt_scene_upload.argtypes = [C.POINTER(pt_prim), i32, C.POINTER(pt_material), i32, i32, C.POINTER(vp)]
+    L.pt_scene_free.argtypes = [vp]
+    L.pt_scene_device.argtypes = [vp]
+    L.pt_render.argtypes = [vp, C.POINTER(pt_config), vp, vp]
+    L.pt_raypath_batch.argtypes = [vp, i32, vp, vp, i32, i32] + [vp] * 9 + [vp]
+    L.pt_nearest_batch.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.pt_trace_paths.argtypes = [vp, vp, vp, vp, vp, i32, u32, i32, i32, vp, vp]
+    L.pt_rng_draws.argtypes = [i32, u32, u32, u32, i32, vp, vp, vp]
+    L.pt_ppm_p3.restype = C.c_long
+    L.pt_ppm_p3.argtypes = [vp, i32, i32, C.c_char_p, C.c_long]
+    return L
+
+
+lib = _load()
+
+EXPORTS = [
+    "pt_scene_upload", "pt_scene_free", "pt_scene_device", "pt_default_scene", "pt_glass_grid_scene",
+    "pt_synthetic_scene", "pt_focal_length", "pt_render", "pt_raypath_batch", "pt_nearest_batch",
+    "pt_trace_paths", "pt_rng_draws", "pt_ppm_p3", "pt_last_error", "pt_version",
+]
+
+
+def _check(rc):
+    if rc != 0:
+        raise PtError(lib.pt_last_error().decode(errors="replace").strip() or ("pt status %d" % rc))
+
+
+def focal_length(nx, ny, v_height=5.0, fov=45.0):
+    """Host-side focal length of main.cu:229-232 (integer nx/ny)."""
+    return float(lib.pt_focal_length(nx, ny, v_height, fov))
+
+
+def default_scene():
+    """The reference's default scene (main.cu:73-195) as (prims, n, mats, n_mats)."""
+    prims = (pt_prim * 11)()
+    mats = (pt_material * 8)()
+    nm = C.c_int(0)
+    n = lib.pt_default_scene(prims, mats, C.byref(nm))
+    return prims, n, mats, nm.value
+
+
+def glass_grid_scene(n):
+    prims = (pt_prim * (8 + n * n))()
+    mats = (pt_material * 8)()
+    nm = C.c_int(0)
+    k = lib.pt_glass_grid_scene(n, prims, mats, C.byref(nm))
+    return prims, k, mats, nm.value
+
+
+def synthetic_scene(n_spheres, n_cubes, seed=12345):
+    prims = (pt_prim * (11 + n_spheres + n_cubes))()
+    mats = (pt_material * 8)()
+    nm = C.c_int(0)
+    k = lib.pt_synthetic_scene(n_spheres, n_cubes, seed, prims, mats, C.byref(nm))
+    return prims, k, mats, nm.value
+
+
+def make_config(width, height, spp, n_bounces=5, seed=0, row_begin=0, row_end=None, camera=(0.0, 0.0, 0.0),
+                fb_layout=PT_FB_AOS, math_mode=PT_MATH_FAST):
+    """config_t of main.cu:234 with the reference's camera (origin, v_height 5, fov 45)."""
+    cfg = pt_config()
+    cfg.camera_pos[:] = camera
+    cfg.max_x, cfg.max_y = width, height
+    cfg.focal_length = focal_length(width, height)
+    cfg.view_port_height = 5.0
+    cfg.n_samples, cfg.n_bounces, cfg.seed = spp, n_bounces, seed
+    cfg.row_begin = row_begin
+    cfg.row_end = height if row_end is None else row_end
+    cfg.fb_layout, cfg.math_mode = fb_layout, math_mode
+    return cfg
+
+
+def ppm_p3(fb):
+    """PPM P3 bytes of a host [H,W,3] float32 framebuffer, as main.cu:240-253 prints it."""
+    fb = np.ascontiguousarray(fb, np.float32)
+    h, w, _ = fb.shape
+    cap = 32 + h * w * 40
+    buf = C.create_string_buffer(cap)
+    n = lib.pt_ppm_p3(fb.ctypes.data_as(C.c_void_p), w, h, buf, cap)
+    if n < 0:
+        raise PtError("pt_ppm_p3: buffer too small")
+    return buf.raw[:n]
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _stream():
+    return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Scene:
+    """Device copy of a scene (pt_scene_upload / pt_scene_free)."""
+
+    def __init__(self, prims, n, mats, n_mats, device=0):
+        self.n, self.n_mats, self.device = n, n_mats, device
+        h = C.c_void_p(0)
+        _check(lib.pt_scene_upload(prims, n, mats, n_mats, device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.pt_scene_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _dev(self):
+        return _torch().device("cuda", self.device)
+
+    def render(self, cfg, out=None):
+        """pt_render into a [H,W,3] (AoS) or [3,H,W] (SoA) float32 device tensor; rows outside the tile are untouched."""
+        torch = _torch()
+        shape = (cfg.max_y, cfg.max_x, 3) if cfg.fb_layout == PT_FB_AOS else (3, cfg.max_y, cfg.max_x)
+        if out is None:
+            out = torch.zeros(shape, dtype=torch.float32, device=self._dev())
+        assert out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == shape
+        with torch.cuda.device(self.device):
+            _check(lib.pt_render(self.h, C.byref(cfg), _ptr(out), _stream()))
+        return out
+
+    def raypath(self, prim, o, d, filter=True):
+        """Shape::getIntersections / getRayPath of one primitive for [n,3] device rays."""
+        torch = _torch()
+        n = o.shape[0]
+        dev = self._dev()
+        res = dict(n=torch.zeros(n, dtype=torch.int32, device=dev))
+        for s in ("1", "2"):
+            res["hit" + s] = torch.zeros(n, dtype=torch.int32, device=dev)
+            res["t" + s] = torch.zeros(n, dtype=torch.float32, device=dev)
+            res["pos" + s] = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+            res["nrm" + s] = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(self.device):
+            _check(lib.pt_raypath_batch(self.h, prim, _ptr(o), _ptr(d), n, 1 if filter else 0, _ptr(res["n"]),
+                                        _ptr(res["hit1"]), _ptr(res["t1"]), _ptr(res["pos1"]), _ptr(res["nrm1"]),
+                                        _ptr(res["hit2"]), _ptr(res["t2"]), _ptr(res["pos2"]), _ptr(res["nrm2"]), _stream()))
+        return res
+
+    def nearest(self, o, d):
+        torch = _torch()
+        n = o.shape[0]
+        dev = self._dev()
+        res = dict(prim=torch.zeros(n, dtype=torch.int32, device=dev), t=torch.zeros(n, dtype=torch.float32, device=dev),
+                   pos=torch.zeros((n, 3), dtype=torch.float32, device=dev),
+                   nrm=torch.zeros((n, 3), dtype=torch.float32, device=dev),
+                   inside=torch.zeros(n, dtype=torch.int32, device=dev))
+        with torch.cuda.device(self.device):
+            _check(lib.pt_nearest_batch(self.h, _ptr(o), _ptr(d), n, _ptr(res["prim"]), _ptr(res["t"]),
+                                        _ptr(res["pos"]), _ptr(res["nrm"]), _ptr(res["inside"]), _stream()))
+        return res
+
+    def trace_paths(self, o, d, pixel, sample, seed=0, n_bounces=5, math_mode=PT_MATH_PARITY):
+        torch = _torch()
+        n = o.shape[0]
+        rgb = torch.zeros((n, 3), dtype=torch.float32, device=self._dev())
+        with torch.cuda.device(self.device):
+            _check(lib.pt_trace_paths(self.h, _ptr(o), _ptr(d), _ptr(pixel), _ptr(sample), n, seed, n_bounces,
+                                      math_mode, _ptr(rgb), _stream()))
+        return rgb
+
+
+def rng_draws(seed, pixel, sample, n_slots, device=0):
+    torch = _torch()
+    dev = torch.device("cuda", device)
+    bits = torch.zeros(n_slots, dtype=torch.int32, device=dev)
+    u = torch.zeros(n_slots, dtype=torch.float32, device=dev)
+    with torch.cuda.device(device):
+        _check(lib.pt_rng_draws(device, seed, pixel, sample, n_slots, _ptr(bits), _ptr(u), _stream()))
+    return bits, u

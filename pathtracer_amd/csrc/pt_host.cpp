@@ -1,0 +1,420 @@
+// Host side of libpt_hip.so: the C entry points of include/pt_hip.h, the scene
+// flattening that replaces constructScene (main.cu:71-198) and the camera set-up
+// of render (main.cu:40-52).  Built with -ffp-contract=off: the table values and
+// camera constants must round exactly as a plain float evaluation does.
+#include "pt_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+const double PT_PI = 3.14159265358979323846;   // vec_math.h:5
+
+// ---- small affine helpers (the Eigen calls of shapes.h:36-38, main.cu:73-134) ----
+struct Aff {
+    float m[3][4];
+};
+Aff aff_identity() {
+    Aff a;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) a.m[i][j] = (i == j) ? 1.0f : 0.0f;
+    return a;
+}
+void aff_translate(Aff& a, float x, float y, float z) { a.m[0][3] = x; a.m[1][3] = y; a.m[2][3] = z; }
+// Affine3f::scale: post-multiplies the linear block, translation untouched.
+void aff_scale(Aff& a, float sx, float sy, float sz) {
+    const float s[3] = {sx, sy, sz};
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a.m[i][j] *= s[j];
+}
+// AngleAxisf(angle, axis).toRotationMatrix() written into the linear block.
+void aff_rotate(Aff& a, float angle, float ax, float ay, float az) {
+    const float s = sinf(angle), c = cosf(angle);
+    const float sx = s * ax, sy = s * ay, sz = s * az;
+    const float c1 = 1.0f - c;
+    const float cx = c1 * ax, cy = c1 * ay, cz = c1 * az;
+    float tmp;
+    tmp = cx * ay; a.m[0][1] = tmp - sz; a.m[1][0] = tmp + sz;
+    tmp = cx * az; a.m[0][2] = tmp + sy; a.m[2][0] = tmp - sy;
+    tmp = cy * az; a.m[1][2] = tmp - sx; a.m[2][1] = tmp + sx;
+    a.m[0][0] = cx * ax + c; a.m[1][1] = cy * ay + c; a.m[2][2] = cz * az + c;
+}
+// Affine inverse: cofactor inverse of the 3x3 block, translation = (-Linv) * t.
+Aff aff_inverse(const Aff& a) {
+    auto cof = [&](int i, int j) {
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        return a.m[i1][j1] * a.m[i2][j2] - a.m[i1][j2] * a.m[i2][j1];
+    };
+    const float c00 = cof(0, 0), c10 = cof(1, 0), c20 = cof(2, 0);
+    const float det = c00 * a.m[0][0] + (c10 * a.m[1][0] + c20 * a.m[2][0]);
+    const float invdet = 1.0f / det;
+    Aff r;
+    for (int row = 0; row < 3; row++)
+        for (int col = 0; col < 3; col++) r.m[row][col] = cof(col, row) * invdet;
+    for (int row = 0; row < 3; row++)
+        r.m[row][3] = (-r.m[row][0]) * a.m[0][3] + ((-r.m[row][1]) * a.m[1][3] + (-r.m[row][2]) * a.m[2][3]);
+    return r;
+}
+void aff_store(const Aff& a, float* out) {
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) out[i * 4 + j] = a.m[i][j];
+}
+Aff aff_load(const float* in) {
+    Aff a;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) a.m[i][j] = in[i * 4 + j];
+    return a;
+}
+
+void mat_defaults(pt_material* m) {   // materials.h:12-38
+    std::memset(m, 0, sizeof(*m));
+    m->IOR = 1.0f;
+}
+void set3(float* d, float x, float y, float z) { d[0] = x; d[1] = y; d[2] = z; }
+
+void put_prim(pt_prim* p, int type, int mat, const Aff& t, float b) {
+    p->type = type; p->material = mat;
+    aff_store(t, p->transform);
+    p->bounds[0] = -b; p->bounds[1] = -b; p->bounds[2] = b; p->bounds[3] = b;
+}
+
+// The eight materials the default scene uses (main.cu:138-183):
+// 0 base, 1 red, 2 green, 3 light, 4 glass1, 5 glass2, 6 glass3, 7 diffuse_pure.
+void default_materials(pt_material* mats) {
+    for (int i = 0; i < 8; i++) mat_defaults(&mats[i]);
+    set3(mats[0].albedo, 0.4f, 0.4f, 0.4f);
+    set3(mats[1].albedo, 1.0f, 0.0f, 0.0f);
+    set3(mats[2].albedo, 0.0f, 1.0f, 0.0f);
+    set3(mats[3].emissive, 1.0f * 20.0f, 0.9f * 20.0f, 0.7f * 20.0f);
+    for (int g = 4; g <= 6; g++) {
+        mats[g].f0 = 0.02f; mats[g].specularRoughness = 0.0f;
+        set3(mats[g].specularColor, 1.0f * 0.8f, 1.0f * 0.8f, 1.0f * 0.8f);
+        mats[g].IOR = 1.5f; mats[g].transparency = 1.0f; mats[g].refractionRoughness = 0.0f; mats[g].bsdfType = 1;
+    }
+    set3(mats[5].refractionColor, 0.9f, 0.0f, 0.0f);
+    set3(mats[6].refractionColor, 2.0f, 0.0f, 0.0f);
+    set3(mats[7].albedo, 0.6f, 0.6f, 0.6f);
+}
+
+// The seven walls of the default scene (main.cu:77-108, 185-191); returns 7.
+int default_walls(pt_prim* prims) {
+    const float HALF_PI = (float)(PT_PI / 2), NEG_HALF_PI = (float)(-PT_PI / 2), FPI = (float)PT_PI;
+    Aff floor = aff_identity(); aff_rotate(floor, HALF_PI, 1, 0, 0); aff_translate(floor, 0.0f, -1.0f, 0.0f);
+    Aff back = aff_identity(); aff_translate(back, 0.0f, 0.0f, -5.0f);
+    Aff left = aff_identity(); aff_rotate(left, HALF_PI, 0, 1, 0); aff_translate(left, -1.0f, 0.0f, -5.0f);
+    Aff right = aff_identity(); aff_rotate(right, NEG_HALF_PI, 0, 1, 0); aff_translate(right, 1.0f, 0.0f, -5.0f);
+    Aff ceiling = aff_identity(); aff_rotate(ceiling, NEG_HALF_PI, 1, 0, 0); aff_translate(ceiling, 0.0f, 1.0f, 0.0f);
+    Aff light = aff_identity(); aff_rotate(light, NEG_HALF_PI, 1, 0, 0); aff_translate(light, 0.0f, 0.97f, -3.25f);
+    Aff front = aff_identity(); aff_rotate(front, FPI, 0, 1, 0); aff_translate(front, 0.0f, 0.0f, 7.0f);
+    put_prim(&prims[0], PT_PLANE, 0, floor, 15.0f);
+    put_prim(&prims[1], PT_PLANE, 1, left, 15.0f);
+    put_prim(&prims[2], PT_PLANE, 2, right, 15.0f);
+    put_prim(&prims[3], PT_PLANE, 0, back, 15.0f);
+    put_prim(&prims[4], PT_PLANE, 0, ceiling, 15.0f);
+    put_prim(&prims[5], PT_PLANE, 3, light, 0.5f);
+    put_prim(&prims[6], PT_PLANE, 0, front, 15.0f);
+    return 7;
+}
+
+uint32_t host_hash(uint32_t x) {
+    x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
+    return x;
+}
+float host_uniform(uint32_t key, uint32_t slot) {
+    const uint32_t bits = host_hash(key ^ (0x85EBCA6Bu * (slot + 1u)));
+    return (float)bits * 2.3283064365386963e-10f + 1.1641532182693481e-10f;
+}
+
+float len3(float x, float y, float z) { return sqrtf(x * x + y * y + z * z); }
+
+// Tag, intersection record and shading record of the fast kernels for one shape.
+void bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, FPrim* fp, FShade* fs, int32_t* ftype) {
+    std::memset(fp, 0, sizeof(*fp));
+    std::memset(fs, 0, sizeof(*fs));
+    fs->type = p.type; fs->material = p.material;
+    // unit columns of L
+    float col[3][3], ncol[3][3];
+    for (int j = 0; j < 3; j++) {
+        for (int i = 0; i < 3; i++) col[j][i] = fwd.m[i][j];
+        const float l = len3(col[j][0], col[j][1], col[j][2]);
+        for (int i = 0; i < 3; i++) ncol[j][i] = l > 0.0f ? col[j][i] / l : col[j][i];
+    }
+    switch (p.type) {
+        case PT_PLANE: {
+            *ftype = FP_PLANE;
+            for (int j = 0; j < 4; j++) { fp->r[j] = inv.m[2][j]; fp->r[4 + j] = inv.m[0][j]; fp->r[8 + j] = inv.m[1][j]; fp->r[12 + j] = p.bounds[j]; }
+            for (int i = 0; i < 3; i++) fs->a[i] = ncol[2][i];
+            break;
+        }
+        case PT_SPHERE: {
+            // L = s * R (orthogonal columns of equal length): the local quadratic
+            // equals the world one with centre t and radius s/2.
+            const float l0 = len3(col[0][0], col[0][1], col[0][2]), l1 = len3(col[1][0], col[1][1], col[1][2]),
+                        l2 = len3(col[2][0], col[2][1], col[2][2]);
+            auto dotc = [&](int a, int b) { return col[a][0] * col[b][0] + col[a][1] * col[b][1] + col[a][2] * col[b][2]; };
+            const float tol = 1e-6f * l0 * l0;
+            const bool uniform = l0 > 0.0f && fabsf(l0 - l1) <= 1e-6f * l0 && fabsf(l0 - l2) <= 1e-6f * l0 &&
+                                 fabsf(dotc(0, 1)) <= tol && fabsf(dotc(0, 2)) <= tol && fabsf(dotc(1, 2)) <= tol;
+            if (uniform) {
+                *ftype = FP_SPHERE_WS;
+                fp->r[0] = fwd.m[0][3]; fp->r[1] = fwd.m[1][3]; fp->r[2] = fwd.m[2][3];
+                const float rad = 0.5f * l0;
+                fp->r[3] = rad * rad;
+            } else {
+                *ftype = FP_SPHERE;
+                for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) fp->r[i * 4 + j] = inv.m[i][j];
+            }
+            fs->a[0] = fwd.m[0][3]; fs->a[1] = fwd.m[1][3]; fs->a[2] = fwd.m[2][3];
+            break;
+        }
+        case PT_CUBE: {
+            *ftype = FP_CUBE;
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) fp->r[i * 4 + j] = inv.m[i][j];
+            for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) fs->a[j * 3 + i] = ncol[j][i];
+            break;
+        }
+        default: {   // PT_CYLINDER
+            *ftype = FP_CYLINDER;
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) fp->r[i * 4 + j] = inv.m[i][j];
+            for (int i = 0; i < 3; i++) { fs->a[i] = col[0][i]; fs->a[3 + i] = col[1][i]; fs->a[6 + i] = ncol[2][i]; }
+            for (int j = 0; j < 4; j++) { fs->a[9 + j] = inv.m[0][j]; fs->a[13 + j] = inv.m[1][j]; }
+            break;
+        }
+    }
+}
+
+}  // namespace
+
+int pt_set_error(int code, const char* expr, const char* file, int line) {
+    std::snprintf(g_err, sizeof(g_err), "HIP error = %u at %s:%d '%s' ", (unsigned)code, file, line, expr);
+    return code ? code : -1;
+}
+#define PT_FAIL(msg) pt_set_error(-1, msg, __FILE__, __LINE__)
+
+extern "C" {
+
+const char* pt_last_error(void) { return g_err; }
+const char* pt_version(void) { return "pathtracer_amd 0.1 (gfx950)"; }
+
+float pt_focal_length(int nx, int ny, float v_height, float fov_deg) {   // main.cu:229-232
+    if (ny == 0) return 0.0f;
+    const float v_width = (float)(nx / ny) * v_height;
+    return (float)((double)(v_width / 2) / tan(((double)(fov_deg / 2) * PT_PI) / 180));
+}
+
+int pt_default_scene(pt_prim* prims, pt_material* mats, int* n_mats) {   // main.cu:73-195
+    default_materials(mats);
+    *n_mats = 8;
+    int n = default_walls(prims);
+    Aff t7 = aff_identity(); aff_translate(t7, -0.6f, -0.5f, -3.0f); aff_scale(t7, 0.4f, 0.4f, 0.4f);
+    Aff t5 = aff_identity(); aff_translate(t5, 0.0f, -0.5f, -3.0f); aff_scale(t5, 0.4f, 0.4f, 0.4f);
+    Aff t6 = aff_identity(); aff_translate(t6, 0.6f, -0.5f, -3.0f); aff_scale(t6, 0.4f, 0.4f, 0.4f);
+    Aff t8 = aff_identity(); aff_translate(t8, 0.0f, -0.5f, -4.2f); aff_scale(t8, 2.5f, 0.3f, 0.5f);
+    put_prim(&prims[n++], PT_SPHERE, 4, t7, 0.0f);
+    put_prim(&prims[n++], PT_SPHERE, 5, t5, 0.0f);
+    put_prim(&prims[n++], PT_SPHERE, 6, t6, 0.0f);
+    put_prim(&prims[n++], PT_CUBE, 7, t8, 0.0f);
+    return n;
+}
+
+int pt_glass_grid_scene(int n, pt_prim* prims, pt_material* mats, int* n_mats) {
+    if (n < 1) return 0;
+    default_materials(mats);
+    *n_mats = 8;
+    int k = default_walls(prims);
+    Aff t8 = aff_identity(); aff_translate(t8, 0.0f, -0.5f, -4.2f); aff_scale(t8, 2.5f, 0.3f, 0.5f);
+    put_prim(&prims[k++], PT_CUBE, 7, t8, 0.0f);
+    // n x n glass spheres in the vertical plane z = -3, x in [-0.8,0.8], y in [-0.8,0.6];
+    // materials cycle glass1/glass2/glass3.
+    const float x0 = -0.8f, x1 = 0.8f, y0 = -0.8f, y1 = 0.6f;
+    const float pitch = n > 1 ? (x1 - x0) / (float)(n - 1) : 0.0f;
+    const float pitch_y = n > 1 ? (y1 - y0) / (float)(n - 1) : 0.0f;
+    const float diam = n > 1 ? 0.8f * fminf(pitch, pitch_y) : 0.4f;
+    for (int r = 0; r < n; r++)
+        for (int c = 0; c < n; c++) {
+            Aff t = aff_identity();
+            aff_translate(t, n > 1 ? x0 + pitch * (float)c : 0.0f, n > 1 ? y0 + pitch_y * (float)r : -0.5f, -3.0f);
+            aff_scale(t, diam, diam, diam);
+            put_prim(&prims[k++], PT_SPHERE, 4 + (r * n + c) % 3, t, 0.0f);
+        }
+    return k;
+}
+
+int pt_synthetic_scene(int n_spheres, int n_cubes, uint32_t seed, pt_prim* prims, pt_material* mats, int* n_mats) {
+    if (n_spheres < 0 || n_cubes < 0) return 0;
+    int k = pt_default_scene(prims, mats, n_mats);
+    // centres uniform in [-0.9,0.9] x [-0.9,0.9] x [-4.9,-1.5], uniform scale in
+    // [0.01,0.03]; materials cycle base, red, green, diffuse_pure, glass1.
+    const int cycle[5] = {0, 1, 2, 7, 4};
+    const uint32_t key = host_hash(seed ^ 0x5bd1e995u);
+    const int total = n_spheres + n_cubes;
+    for (int i = 0; i < total; i++) {
+        const uint32_t b = (uint32_t)i * 4u;
+        const float ux = host_uniform(key, b), uy = host_uniform(key, b + 1), uz = host_uniform(key, b + 2), us = host_uniform(key, b + 3);
+        const float s = 0.01f + 0.02f * us;
+        Aff t = aff_identity();
+        aff_translate(t, -0.9f + 1.8f * ux, -0.9f + 1.8f * uy, -4.9f + 3.4f * uz);
+        aff_scale(t, s, s, s);
+        put_prim(&prims[k++], i < n_spheres ? PT_SPHERE : PT_CUBE, cycle[i % 5], t, 0.0f);
+    }
+    return k;
+}
+
+int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, int n_mats, int device, pt_scene** out) {
+    if (!prims || !mats || !out || n_prims <= 0 || n_mats <= 0) return PT_FAIL("pt_scene_upload: bad arguments");
+    for (int k = 0; k < n_prims; k++) {
+        if (prims[k].type < PT_PLANE || prims[k].type > PT_SPHERE) return PT_FAIL("pt_scene_upload: unknown shape type");
+        if (prims[k].material < 0 || prims[k].material >= n_mats) return PT_FAIL("pt_scene_upload: material index out of range");
+    }
+    PT_CHECK(hipSetDevice(device));
+    std::vector<DPrim> dp(n_prims);
+    std::vector<FPrim> fp(n_prims);
+    std::vector<FShade> fs(n_prims);
+    std::vector<int32_t> ft(n_prims);
+    for (int k = 0; k < n_prims; k++) {
+        const Aff fwd = aff_load(prims[k].transform);
+        const Aff inv = aff_inverse(fwd);
+        aff_store(inv, dp[k].inv);
+        aff_store(fwd, dp[k].fwd);
+        for (int j = 0; j < 4; j++) dp[k].bounds[j] = prims[k].bounds[j];
+        dp[k].type = prims[k].type; dp[k].material = prims[k].material; dp[k].pad[0] = dp[k].pad[1] = 0;
+        bake_fast(prims[k], fwd, inv, &fp[k], &fs[k], &ft[k]);
+    }
+    std::vector<DMat> dm(n_mats);
+    for (int i = 0; i < n_mats; i++) {
+        std::memset(&dm[i], 0, sizeof(DMat));
+        std::memcpy(&dm[i], &mats[i], sizeof(pt_material));
+    }
+    pt_scene* sc = new (std::nothrow) pt_scene();
+    if (!sc) return PT_FAIL("pt_scene_upload: out of host memory");
+    std::memset(sc, 0, sizeof(*sc));
+    sc->device = device; sc->n_prims = n_prims; sc->n_mats = n_mats;
+    hipError_t e;
+#define UP(dst, vec, T)                                                                        \
+    e = hipMalloc((void**)&sc->dst, vec.size() * sizeof(T));                                   \
+    if (e == hipSuccess) e = hipMemcpy(sc->dst, vec.data(), vec.size() * sizeof(T), hipMemcpyHostToDevice); \
+    if (e != hipSuccess) { pt_scene_free(sc); return pt_set_error((int)e, "scene upload " #dst, __FILE__, __LINE__); }
+    UP(d_prims, dp, DPrim)
+    UP(d_mats, dm, DMat)
+    UP(d_fprims, fp, FPrim)
+    UP(d_fshade, fs, FShade)
+    UP(d_ftype, ft, int32_t)
+#undef UP
+    *out = sc;
+    return 0;
+}
+
+int pt_scene_free(pt_scene* sc) {
+    if (!sc) return 0;
+    (void)hipSetDevice(sc->device);
+    if (sc->d_prims) (void)hipFree(sc->d_prims);
+    if (sc->d_mats) (void)hipFree(sc->d_mats);
+    if (sc->d_fprims) (void)hipFree(sc->d_fprims);
+    if (sc->d_fshade) (void)hipFree(sc->d_fshade);
+    if (sc->d_ftype) (void)hipFree(sc->d_ftype);
+    delete sc;
+    return 0;
+}
+
+int pt_scene_device(const pt_scene* sc) { return sc ? sc->device : -1; }
+
+int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* stream) {
+    if (!sc || !cfg || !d_fb) return PT_FAIL("pt_render: null argument");
+    if (cfg->max_x <= 0 || cfg->max_y <= 0 || cfg->n_samples <= 0 || cfg->n_bounces < 0)
+        return PT_FAIL("pt_render: bad image size, n_samples or n_bounces");
+    if (cfg->n_samples > (1 << 24)) return PT_FAIL("pt_render: n_samples above 2^24");
+    if ((uint64_t)cfg->max_x * (uint64_t)cfg->max_y > 0x7fffffffull) return PT_FAIL("pt_render: image above 2^31 pixels");
+    if (cfg->row_begin < 0 || cfg->row_end > cfg->max_y || cfg->row_begin > cfg->row_end)
+        return PT_FAIL("pt_render: row tile outside the image");
+    if (cfg->fb_layout != PT_FB_AOS && cfg->fb_layout != PT_FB_SOA) return PT_FAIL("pt_render: unknown fb_layout");
+    PT_CHECK(hipSetDevice(sc->device));
+    RenderArgs a;
+    std::memset(&a, 0, sizeof(a));
+    // main.cu:40-52, one float operation at a time.
+    const float vh = cfg->view_port_height;
+    const float vw = vh * ((float)cfg->max_x / cfg->max_y);
+    const float vu[3] = {vw, 0.0f, 0.0f}, vv[3] = {0.0f, -vh, 0.0f};
+    float du[3], dv[3], ul[3];
+    const float foc[3] = {0.0f, 0.0f, cfg->focal_length};
+    for (int c = 0; c < 3; c++) {
+        du[c] = vu[c] / (float)cfg->max_x;
+        dv[c] = vv[c] / (float)cfg->max_y;
+        ul[c] = ((cfg->camera_pos[c] - foc[c]) - vu[c] / 2.0f) - vv[c] / 2.0f;
+        a.p00[c] = ul[c] + (du[c] + dv[c]) * 0.5f;
+        a.cam[c] = cfg->camera_pos[c];
+    }
+    a.du = du[0]; a.dv = dv[1];
+    a.max_x = cfg->max_x; a.max_y = cfg->max_y;
+    a.n_samples = cfg->n_samples; a.n_bounces = cfg->n_bounces;
+    a.seed_hash = host_hash(cfg->seed + 0x9E3779B9u);
+    a.pix_begin = (uint32_t)cfg->row_begin * (uint32_t)cfg->max_x;
+    a.pix_end = (uint32_t)cfg->row_end * (uint32_t)cfg->max_x;
+    a.fb_layout = cfg->fb_layout;
+    a.n_prims = sc->n_prims; a.n_mats = sc->n_mats;
+    a.prims = sc->d_prims; a.mats = sc->d_mats;
+    a.fprims = sc->d_fprims; a.fshade = sc->d_fshade; a.ftype = sc->d_ftype;
+    a.fb = d_fb;
+    if (cfg->math_mode == PT_MATH_PARITY) return ptk_render_parity(a, (hipStream_t)stream);
+    if (cfg->math_mode == PT_MATH_FAST) return ptk_render_fast(a, (hipStream_t)stream);
+    return PT_FAIL("pt_render: unknown math_mode");
+}
+
+int pt_raypath_batch(const pt_scene* sc, int prim, const float* d_o, const float* d_d, int n_rays, int filter,
+                     int32_t* d_n, int32_t* d_hit1, float* d_t1, float* d_pos1, float* d_nrm1,
+                     int32_t* d_hit2, float* d_t2, float* d_pos2, float* d_nrm2, void* stream) {
+    if (!sc || !d_o || !d_d || n_rays < 0) return PT_FAIL("pt_raypath_batch: bad arguments");
+    if (prim < 0 || prim >= sc->n_prims) return PT_FAIL("pt_raypath_batch: primitive index out of range");
+    PT_CHECK(hipSetDevice(sc->device));
+    return ptk_raypath_batch(sc, prim, d_o, d_d, n_rays, filter, d_n, d_hit1, d_t1, d_pos1, d_nrm1,
+                             d_hit2, d_t2, d_pos2, d_nrm2, (hipStream_t)stream);
+}
+
+int pt_nearest_batch(const pt_scene* sc, const float* d_o, const float* d_d, int n_rays,
+                     int32_t* d_prim, float* d_t, float* d_pos, float* d_nrm, int32_t* d_inside, void* stream) {
+    if (!sc || !d_o || !d_d || n_rays < 0) return PT_FAIL("pt_nearest_batch: bad arguments");
+    PT_CHECK(hipSetDevice(sc->device));
+    return ptk_nearest_batch(sc, d_o, d_d, n_rays, d_prim, d_t, d_pos, d_nrm, d_inside, (hipStream_t)stream);
+}
+
+int pt_trace_paths(const pt_scene* sc, const float* d_o, const float* d_d, const uint32_t* d_pixel,
+                   const uint32_t* d_sample, int n_rays, uint32_t seed, int n_bounces, int math_mode,
+                   float* d_rgb, void* stream) {
+    if (!sc || !d_o || !d_d || !d_pixel || !d_sample || !d_rgb || n_rays < 0 || n_bounces < 0)
+        return PT_FAIL("pt_trace_paths: bad arguments");
+    PT_CHECK(hipSetDevice(sc->device));
+    const uint32_t sh = host_hash(seed + 0x9E3779B9u);
+    if (math_mode == PT_MATH_PARITY)
+        return ptk_trace_paths_parity(sc, d_o, d_d, d_pixel, d_sample, n_rays, sh, n_bounces, d_rgb, (hipStream_t)stream);
+    if (math_mode == PT_MATH_FAST)
+        return ptk_trace_paths_fast(sc, d_o, d_d, d_pixel, d_sample, n_rays, sh, n_bounces, d_rgb, (hipStream_t)stream);
+    return PT_FAIL("pt_trace_paths: unknown math_mode");
+}
+
+int pt_rng_draws(int device, uint32_t seed, uint32_t pixel, uint32_t sample, int n_slots,
+                 uint32_t* d_bits, float* d_uniforms, void* stream) {
+    if (n_slots < 0) return PT_FAIL("pt_rng_draws: bad arguments");
+    PT_CHECK(hipSetDevice(device));
+    return ptk_rng_draws(host_hash(seed + 0x9E3779B9u), pixel, sample, n_slots, d_bits, d_uniforms, (hipStream_t)stream);
+}
+
+long pt_ppm_p3(const float* fb, int nx, int ny, char* out, long cap) {   // main.cu:240-253
+    long n = 0;
+    int w = std::snprintf(out, (size_t)cap, "P3\n%d %d\n255\n", nx, ny);
+    if (w < 0 || w >= cap) return -1;
+    n += w;
+    for (int j = ny - 1; j >= 0; j--) {
+        for (int i = 0; i < nx; i++) {
+            const size_t pixel_index = (size_t)j * nx + i;
+            const float r = fb[pixel_index * 3], g = fb[pixel_index * 3 + 1], b = fb[pixel_index * 3 + 2];
+            const int ir = int(255.99 * r), ig = int(255.99 * g), ib = int(255.99 * b);
+            w = std::snprintf(out + n, (size_t)(cap - n), "%d %d %d\n", ir, ig, ib);
+            if (w < 0 || w >= cap - n) return -1;
+            n += w;
+        }
+    }
+    return n;
+}
+
+}  // extern "C"

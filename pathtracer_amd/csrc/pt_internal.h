@@ -1,0 +1,110 @@
+// Shared between the host side of libpt_hip and its kernels: the device
+// primitive table, the launch argument blocks and the error plumbing.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pt_hip.h"
+
+// One primitive of the tagged-union table used by the parity-order kernels.
+// The record is wave-uniform data: kernels index it with a uniform k so the
+// compiler fetches it with scalar loads.  128 bytes.
+struct DPrim {
+    float inv[12];    // rows of transform_inv  (shapes.h:37)
+    float fwd[12];    // rows of transform; wOrigin = (fwd[3], fwd[7], fwd[11]) (shapes.h:36,38)
+    float bounds[4];  // Plane xMin, yMin, xMax, yMax (shapes.h:105-109)
+    int32_t type;
+    int32_t material;
+    int32_t pad[2];
+};
+
+// Material padded to 80 bytes so a lane can fetch it with five 16-byte reads.
+struct DMat {
+    float albedo[3];
+    float emissive[3];
+    float f0;
+    float specularRoughness;
+    float specularColor[3];
+    float IOR;
+    float transparency;
+    float refractionRoughness;
+    float refractionColor[3];
+    int32_t bsdfType;
+    float pad[2];
+};
+
+// Intersection record of the fast kernels: 16 floats, one s_load_dwordx16.
+//   plane : r0 = row z of T^-1 (local o.z, d.z), r1 = row x, r2 = row y, r3 = bounds
+//   sphere (uniform scale): r0 = centre.xyz, radius^2 ; rest unused
+//   sphere (general), cube, cylinder: r0..r2 = rows of T^-1
+struct FPrim {
+    float r[16];
+};
+// Shading record of the fast kernels, fetched per lane for the winning primitive.
+//   plane   : a[0..2] = unit world normal (third column of L)
+//   sphere  : a[0..2] = centre (translation)
+//   cube    : a[3j..3j+2] = unit column j of L
+//   cylinder: a[0..2], a[3..5] = columns 0,1 of L, a[6..8] = unit column 2,
+//             a[9..12], a[13..16] = rows x,y of T^-1
+struct FShade {
+    float a[20];
+    int32_t type;
+    int32_t material;
+    int32_t pad[2];
+};
+
+enum { FP_PLANE = 0, FP_CUBE = 1, FP_CYLINDER = 2, FP_SPHERE = 3, FP_SPHERE_WS = 4 };
+
+struct pt_scene {
+    int device;
+    int n_prims;
+    int n_mats;
+    DPrim* d_prims;
+    DMat* d_mats;
+    FPrim* d_fprims;
+    FShade* d_fshade;
+    int32_t* d_ftype;      // fast-kernel tag per primitive (FP_*)
+};
+
+// Camera constants computed on the host in the reference's operation order
+// (main.cu:40-52) and the per-launch parameters of the render kernels.
+struct RenderArgs {
+    float cam[3];
+    float p00[3];          // pixel00_loc
+    float du, dv;          // pixel_delta_u.x, pixel_delta_v.y
+    int32_t max_x, max_y;
+    int32_t n_samples, n_bounces;
+    uint32_t seed_hash;    // H(seed + 0x9E3779B9)
+    uint32_t pix_begin, pix_end;   // linear pixel range [row_begin*max_x, row_end*max_x)
+    int32_t fb_layout;
+    int32_t n_prims, n_mats;
+    const DPrim* prims;
+    const DMat* mats;
+    const FPrim* fprims;
+    const FShade* fshade;
+    const int32_t* ftype;
+    float* fb;
+};
+
+// Kernel launchers implemented in the .hip translation units.
+int ptk_render_parity(const RenderArgs& a, hipStream_t s);
+int ptk_render_fast(const RenderArgs& a, hipStream_t s);
+int ptk_raypath_batch(const pt_scene* sc, int prim, const float* o, const float* d, int n, int filter,
+                      int32_t* dn, int32_t* h1, float* t1, float* p1, float* n1,
+                      int32_t* h2, float* t2, float* p2, float* n2, hipStream_t s);
+int ptk_nearest_batch(const pt_scene* sc, const float* o, const float* d, int n, int32_t* prim, float* t,
+                      float* pos, float* nrm, int32_t* inside, hipStream_t s);
+int ptk_trace_paths_parity(const pt_scene* sc, const float* o, const float* d, const uint32_t* pixel,
+                           const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, float* rgb, hipStream_t s);
+int ptk_trace_paths_fast(const pt_scene* sc, const float* o, const float* d, const uint32_t* pixel,
+                         const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, float* rgb, hipStream_t s);
+int ptk_rng_draws(uint32_t seed_hash, uint32_t pixel, uint32_t sample, int n_slots, uint32_t* bits, float* u, hipStream_t s);
+
+// Records "HIP error = <n> at <file>:<line> '<expr>'" for pt_last_error().
+int pt_set_error(int code, const char* expr, const char* file, int line);
+#define PT_CHECK(expr)                                                        \
+    do {                                                                      \
+        hipError_t _e = (expr);                                               \
+        if (_e != hipSuccess) return pt_set_error((int)_e, #expr, __FILE__, __LINE__); \
+    } while (0)

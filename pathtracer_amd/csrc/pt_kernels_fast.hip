@@ -1,0 +1,428 @@
+// Fast-math render and tracePath kernels for gfx950.
+//
+// Same algorithm, same counter-RNG streams and same branch structure as the
+// parity-order kernels, but written for VALU throughput:
+//  * the primitive loop reads 16-float intersection records through scalar
+//    loads (k is wave-uniform), so the records live in SGPRs and cost no VGPRs
+//    and no LDS bandwidth;
+//  * planes are tested as t = -(n.o + w) / (n.d) with the bounds check on two
+//    more rows of T^-1; uniformly scaled spheres are tested in world space;
+//    cubes keep the slab test and remember the face axis so the normal needs no
+//    second transform;
+//  * the hit position is o + d*t in world space; normals come from a per-
+//    primitive shading record gathered from LDS for the winner only;
+//  * v_rcp/v_rsq/v_sqrt/v_exp and v_sin/v_cos (which take revolutions, so the
+//    2*pi multiply of bsdf.h:31 disappears), FMA contraction everywhere.
+// Results differ from the parity-order kernels by rounding only.
+#include "pt_internal.h"
+#include "pt_wavepool.h"
+
+#define PTD __device__ __forceinline__
+
+namespace ptf {
+
+struct V3 { float x, y, z; };
+PTD V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+PTD V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PTD V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PTD V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+PTD V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PTD V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
+PTD float dot(V3 a, V3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z)); }
+PTD V3 madd(V3 d, float t, V3 o) { return v3(__builtin_fmaf(d.x, t, o.x), __builtin_fmaf(d.y, t, o.y), __builtin_fmaf(d.z, t, o.z)); }
+PTD float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+PTD float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+PTD float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+PTD float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+PTD float max3(float a, float b, float c) { return __builtin_fmaxf(a, __builtin_fmaxf(b, c)); }
+PTD float min3(float a, float b, float c) { return __builtin_fminf(a, __builtin_fminf(b, c)); }
+// Unit vector; the caller guarantees a non-zero input.
+PTD V3 unit(V3 a) { return a * rsq(dot(a, a)); }
+// Unit vector that leaves the zero vector alone (Eigen's normalized()).
+PTD V3 unit_or_zero(V3 a) { float n = dot(a, a); return n > 0.0f ? a * rsq(n) : a; }
+// row . (p, 1)
+PTD float row_point(const float* r, V3 p) { return __builtin_fmaf(r[0], p.x, __builtin_fmaf(r[1], p.y, __builtin_fmaf(r[2], p.z, r[3]))); }
+PTD float row_vec(const float* r, V3 p) { return __builtin_fmaf(r[0], p.x, __builtin_fmaf(r[1], p.y, r[2] * p.z)); }
+
+// ---- counter RNG: identical integer streams to the parity-order kernels ------
+PTD uint32_t rng_hash(uint32_t x) {
+    x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
+    return x;
+}
+PTD float rng_u(uint32_t key, uint32_t slot) {
+    const uint32_t bits = rng_hash(key ^ (0x85EBCA6Bu * (slot + 1u)));
+    return __builtin_fmaf((float)bits, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+}
+
+constexpr float EPS = 1e-5f;   // SMALL_NUMBER (vec_math.h:7) as the float predicate t <= 1e-5
+
+struct Best {
+    float t;      // +inf = miss
+    int prim;
+    int code;     // cube: face axis 0..2, bit 2 = exit face; cylinder: surface 0 body, 1 disc +z, 2 disc -z
+};
+
+// One primitive against one ray.  `R` is the wave-uniform record.
+PTD void test_plane(const float* R, V3 o, V3 d, int k, Best& b) {
+    const float oz = row_point(R, o);
+    const float dz = row_vec(R, d);
+    const float t = -oz * rcp(dz);                 // dz == 0 gives inf/nan: every compare below fails
+    const V3 p = madd(d, t, o);
+    const float xl = row_point(R + 4, p), yl = row_point(R + 8, p);
+    const bool ok = (t > EPS) & (t < b.t) & (xl > R[12]) & (yl > R[13]) & (xl < R[14]) & (yl < R[15]);
+    if (ok) { b.t = t; b.prim = k; b.code = 0; }
+}
+
+// Quadratic a t^2 + 2 h t + c = 0 (h = half the linear coefficient): picks the
+// root Shape::getIntersections + getNearestIntersection would keep.
+PTD void take_quadratic(float a, float h, float c, int k, Best& b) {
+    const float disc = __builtin_fmaf(h, h, -a * c);
+    const float s = fsqrt(disc);
+    const float ia = rcp(a);
+    const float t1 = (-h - s) * ia, t2 = (s - h) * ia;
+    const float t = t1 > EPS ? t1 : t2;
+    const bool ok = (disc >= 0.0f) & (t > EPS) & (t < b.t);
+    if (ok) { b.t = t; b.prim = k; b.code = 0; }
+}
+
+PTD void test_sphere_ws(const float* R, V3 o, V3 d, float dd, int k, Best& b) {
+    const V3 oc = o - v3(R[0], R[1], R[2]);
+    take_quadratic(dd, dot(oc, d), dot(oc, oc) - R[3], k, b);
+}
+
+PTD void test_sphere(const float* R, V3 o, V3 d, int k, Best& b) {
+    const V3 ol = v3(row_point(R, o), row_point(R + 4, o), row_point(R + 8, o));
+    const V3 dl = v3(row_vec(R, d), row_vec(R + 4, d), row_vec(R + 8, d));
+    take_quadratic(dot(dl, dl), dot(dl, ol), dot(ol, ol) - 0.25f, k, b);
+}
+
+PTD void test_cube(const float* R, V3 o, V3 d, int k, Best& b) {
+    const V3 ol = v3(row_point(R, o), row_point(R + 4, o), row_point(R + 8, o));
+    const V3 dl = v3(row_vec(R, d), row_vec(R + 4, d), row_vec(R + 8, d));
+    const float ix = rcp(dl.x), iy = rcp(dl.y), iz = rcp(dl.z);
+    const float hx = 0.5f * __builtin_fabsf(ix), hy = 0.5f * __builtin_fabsf(iy), hz = 0.5f * __builtin_fabsf(iz);
+    const float cx = -ol.x * ix, cy = -ol.y * iy, cz = -ol.z * iz;
+    const float nx = cx - hx, ny = cy - hy, nz = cz - hz;   // entry distance per slab
+    const float fx = cx + hx, fy = cy + hy, fz = cz + hz;   // exit distance per slab
+    const float tmin = max3(nx, ny, nz), tmax = min3(fx, fy, fz);
+    const bool use_exit = !(tmin > EPS);
+    const float t = use_exit ? tmax : tmin;
+    const bool ok = (tmax >= 0.0f) & (tmin <= tmax) & (t > EPS) & (t < b.t);
+    if (ok) {
+        const float ax = use_exit ? fx : nx, ay = use_exit ? fy : ny;
+        const int axis = (ax == t) ? 0 : ((ay == t) ? 1 : 2);
+        b.t = t; b.prim = k; b.code = axis | (use_exit ? 4 : 0);
+    }
+}
+
+// Cylinder: the case analysis of shapes.h:231-318 in local space.
+PTD void test_cylinder(const float* R, V3 o, V3 d, int k, Best& b) {
+    const V3 ol = v3(row_point(R, o), row_point(R + 4, o), row_point(R + 8, o));
+    const V3 dl = v3(row_vec(R, d), row_vec(R + 4, d), row_vec(R + 8, d));
+    const float a = __builtin_fmaf(dl.x, dl.x, dl.y * dl.y);
+    const float h = __builtin_fmaf(dl.x, ol.x, dl.y * ol.y);
+    const float c = __builtin_fmaf(ol.x, ol.x, ol.y * ol.y) - 0.25f;
+    const float disc = __builtin_fmaf(h, h, -a * c);
+    const float iz = rcp(dl.z);
+    const float td1 = (0.5f - ol.z) * iz, td2 = (-0.5f - ol.z) * iz;
+    bool d1 = false, d2 = false;
+    if (dl.z != 0.0f) {
+        const float x1 = __builtin_fmaf(dl.x, td1, ol.x), y1 = __builtin_fmaf(dl.y, td1, ol.y);
+        const float x2 = __builtin_fmaf(dl.x, td2, ol.x), y2 = __builtin_fmaf(dl.y, td2, ol.y);
+        d1 = !(__builtin_fmaf(x1, x1, y1 * y1) > 0.25f);
+        d2 = !(__builtin_fmaf(x2, x2, y2 * y2) > 0.25f);
+    }
+    bool c1 = false, c2 = false;
+    float tc1 = 0.0f, tc2 = 0.0f;
+    if (disc > 0.0f) {
+        const float s = fsqrt(disc), ia = rcp(a);
+        tc1 = (-h - s) * ia; tc2 = (s - h) * ia;
+        const float z1 = __builtin_fmaf(dl.z, tc1, ol.z), z2 = __builtin_fmaf(dl.z, tc2, ol.z);
+        c1 = (-0.5f < z1) & (z1 < 0.5f);
+        c2 = (-0.5f < z2) & (z2 < 0.5f);
+    }
+    int n = 0; bool h1 = false, h2 = false; float t1 = 0.0f, t2 = 0.0f; int s1 = 0, s2 = 0;
+    if (d1 && d2) { n = 2; h1 = true; t1 = td1; s1 = 1; h2 = true; t2 = td2; s2 = 2; }
+    else if (d1 && disc > 0.0f) { n = 2; h1 = true; t1 = td1; s1 = 1; h2 = c1 ? c1 : c2; t2 = c1 ? tc1 : tc2; s2 = 0; }
+    else if (d2 && disc > 0.0f) { n = 2; h1 = true; t1 = td2; s1 = 2; h2 = c1 ? c1 : c2; t2 = c1 ? tc1 : tc2; s2 = 0; }
+    else if (disc > 0.0f && c1 && c2) { n = 2; h1 = true; t1 = tc1; s1 = 0; h2 = true; t2 = tc2; s2 = 0; }
+    if (n == 2) {
+        const bool e1 = t1 <= EPS, e2 = t2 <= EPS;
+        bool valid; float t; int s;
+        if (e1 && e2) { valid = false; t = 0.0f; s = 0; }
+        else if (e1) { valid = h2; t = t2; s = s2; }
+        else if (e2) { valid = h1; t = t1; s = s1; }
+        else { const bool sec = t2 < t1; valid = sec ? h2 : h1; t = sec ? t2 : t1; s = sec ? s2 : s1; }
+        if (valid && t < b.t) { b.t = t; b.prim = k; b.code = s; }
+    }
+}
+
+// getNearestIntersection (shapes.h:79-100) over the whole table.
+PTD Best nearest(V3 o, V3 d, const FPrim* __restrict__ recs, const int32_t* __restrict__ tags, int n) {
+    Best b; b.t = __builtin_inff(); b.prim = -1; b.code = 0;
+    const float dd = dot(d, d);
+    for (int k = 0; k < n; k++) {
+        const float* R = recs[k].r;
+        switch (tags[k]) {
+            case FP_PLANE: test_plane(R, o, d, k, b); break;
+            case FP_SPHERE_WS: test_sphere_ws(R, o, d, dd, k, b); break;
+            case FP_CUBE: test_cube(R, o, d, k, b); break;
+            case FP_SPHERE: test_sphere(R, o, d, k, b); break;
+            default: test_cylinder(R, o, d, k, b); break;
+        }
+    }
+    return b;
+}
+
+struct Surf {
+    V3 pos, nrm;     // world position; unit normal facing against the ray
+    bool inside;
+    int material;
+};
+
+// The winner's record: position, facing normal and the inside flag of
+// shapes.h:93-97, from the per-primitive shading record.
+PTD Surf surface(const Best& b, V3 o, V3 d, const FShade* shade) {
+    Surf s;
+    const FShade& S = shade[b.prim];
+    s.material = S.material;
+    s.pos = madd(d, b.t, o);
+    const int type = S.type;
+    V3 n;
+    bool inside_known = false, inside = false;
+    if (type == PT_CYLINDER) {
+        if (b.code == 0) {
+            const float x = row_point(S.a + 9, s.pos), y = row_point(S.a + 13, s.pos);
+            n = unit_or_zero(v3(__builtin_fmaf(S.a[0], x, S.a[3] * y), __builtin_fmaf(S.a[1], x, S.a[4] * y), __builtin_fmaf(S.a[2], x, S.a[5] * y)));
+        } else {
+            const float sg = b.code == 1 ? 1.0f : -1.0f;
+            n = v3(S.a[6] * sg, S.a[7] * sg, S.a[8] * sg);
+        }
+    } else {
+        const int off = type == PT_CUBE ? (b.code & 3) * 3 : 0;
+        n = v3(S.a[off], S.a[off + 1], S.a[off + 2]);
+        if (type == PT_SPHERE) n = unit_or_zero(s.pos - n);
+        if (type == PT_PLANE) { inside_known = true; inside = false; }
+        if (type == PT_CUBE) { inside_known = true; inside = (b.code & 4) != 0; }
+    }
+    const bool along = dot(n, d) > 0.0f;
+    s.inside = inside_known ? inside : along;
+    s.nrm = along ? neg(n) : n;
+    return s;
+}
+
+PTD V3 sphere_point(float u1, float u2) {            // bsdf.h:29-36; v_sin/v_cos take revolutions
+    const float z = __builtin_fmaf(u1, 2.0f, -1.0f);
+    const float r = fsqrt(__builtin_fmaxf(__builtin_fmaf(-z, z, 1.0f), 0.0f));
+    return v3(r * __builtin_amdgcn_cosf(u2), r * __builtin_amdgcn_sinf(u2), z);
+}
+
+PTD float fresnel_ratio(V3 dir, V3 nrm, float f0, float n1, float n2) {   // bsdf.h:48-69 with f90 = 1
+    float cX = -dot(dir, nrm);
+    if (n1 > n2) {
+        const float n = n1 * rcp(n2);
+        const float s2 = n * n * __builtin_fmaf(-cX, cX, 1.0f);
+        if (s2 > 1.0f) return 1.0f;
+        cX = fsqrt(1.0f - s2);
+    }
+    const float q = (n1 - n2) * rcp(n1 + n2);
+    const float r0 = q * q;
+    const float m = 1.0f - cX;
+    const float m2 = m * m;
+    const float fr = __builtin_fmaf(1.0f - r0, m2 * m2 * m, r0);
+    return __builtin_fmaf(1.0f - fr, f0, fr);          // lerp(f0, 1, fr)
+}
+
+struct Path {
+    V3 o, d, coef, contrib;
+    uint32_t key;
+    int seg;
+};
+
+// One iteration of the tracePath loop (bsdf.h:78-166); true = continue.
+PTD bool path_step(Path& p, const FPrim* __restrict__ recs, const int32_t* __restrict__ tags, int n_prims,
+                   const FShade* shade, const DMat* mats, int n_bounces) {
+    const Best b = nearest(p.o, p.d, recs, tags, n_prims);
+    if (b.prim < 0) return false;
+    const Surf s = surface(b, p.o, p.d, shade);
+    const DMat& M = mats[s.material];
+    const V3 em = v3(M.emissive[0], M.emissive[1], M.emissive[2]);
+    if ((max3(em.x, em.y, em.z) > 0.0f) || (min3(em.x, em.y, em.z) < 0.0f)) p.contrib = v3(__builtin_fmaf(em.x, p.coef.x, p.contrib.x), __builtin_fmaf(em.y, p.coef.y, p.contrib.y), __builtin_fmaf(em.z, p.coef.z, p.contrib.z));
+    const float f0 = M.f0, transparency = M.transparency;
+    float p_specular = f0, p_refract = transparency;
+    const bool glassy = (f0 > 0.0f) || (transparency > 0.0f);
+    float ior = 1.0f;
+    if (p.seg > 0 && s.inside) {                       // Beer attenuation, bsdf.h:95-98
+        const V3 rc = v3(M.refractionColor[0], M.refractionColor[1], M.refractionColor[2]);
+        p.coef = p.coef * v3(fexp(-rc.x * b.t), fexp(-rc.y * b.t), fexp(-rc.z * b.t));
+    }
+    if (glassy) {
+        ior = M.IOR;
+        if (f0 > 0.0f) {
+            p_specular = fresnel_ratio(p.d, s.nrm, f0, s.inside ? ior : 1.0f, s.inside ? 1.0f : ior);
+            p_refract = transparency * (1.0f - p_specular) * rcp(1.0f - f0);
+        }
+    }
+    const uint32_t slot = 2u + 6u * (uint32_t)p.seg;
+    int mode = 3;
+    float p_ray = 1.0f - (p_specular + p_refract);
+    if (glassy) {
+        const float u = rng_u(p.key, slot);
+        if (p_specular > 0.0f && u < p_specular) { mode = 1; p_ray = p_specular; }
+        else if (p_refract > 0.0f && u < p_specular + p_refract) { mode = 2; p_ray = p_refract; }
+    }
+    p_ray = __builtin_fmaxf(p_ray, 0.001f);
+    V3 ndir;
+    V3 tint;
+    if (mode == 2) {
+        const float eta = s.inside ? ior : rcp(ior);
+        const float ndi = dot(s.nrm, p.d);
+        const float k = __builtin_fmaf(-eta * eta, __builtin_fmaf(-ndi, ndi, 1.0f), 1.0f);
+        V3 rd = v3(0.0f, 0.0f, 0.0f);
+        if (!(k < 0.0f)) rd = unit_or_zero(madd(s.nrm, -__builtin_fmaf(eta, ndi, fsqrt(k)), p.d * eta));
+        const float rr = M.refractionRoughness * M.refractionRoughness;
+        if (rr != 0.0f) {
+            const V3 hd = unit_or_zero(s.nrm + sphere_point(rng_u(p.key, slot + 3u), rng_u(p.key, slot + 4u)));
+            rd = unit_or_zero(madd(hd, rr, rd * (1.0f - rr)));
+        }
+        ndir = rd;
+        tint = v3(1.0f, 1.0f, 1.0f);
+    } else {
+        const V3 dd = unit_or_zero(s.nrm + sphere_point(rng_u(p.key, slot + 1u), rng_u(p.key, slot + 2u)));
+        if (mode == 1) {
+            V3 sd = unit_or_zero(madd(s.nrm, -2.0f * dot(p.d, s.nrm), p.d));
+            const float sr = M.specularRoughness * M.specularRoughness;
+            if (sr != 0.0f) sd = unit_or_zero(madd(dd, sr, sd * (1.0f - sr)));
+            ndir = sd;
+            tint = v3(M.specularColor[0], M.specularColor[1], M.specularColor[2]);
+        } else {
+            ndir = dd;
+            tint = v3(M.albedo[0], M.albedo[1], M.albedo[2]);
+        }
+    }
+    p.coef = p.coef * tint * rcp(p_ray);
+    const float q = max3(p.coef.x, p.coef.y, p.coef.z);
+    // Russian roulette (bsdf.h:160-164): u in (0,1], so q >= 1 always survives
+    // and q <= 0 never does; only 0 < q < 1 (or NaN) needs the draw.
+    if (q <= 0.0f) return false;
+    if (!(q >= 1.0f)) {
+        if (rng_u(p.key, slot + 5u) > q) return false;
+    }
+    p.coef = p.coef * rcp(q);
+    p.o = s.pos;
+    p.d = ndir;
+    p.seg++;
+    return p.seg <= n_bounces;
+}
+
+}  // namespace ptf
+
+namespace {
+
+using namespace ptf;
+
+constexpr int LDS_MAX_PRIMS = 64;   // shading records kept in LDS up to this many primitives
+constexpr int LDS_MAX_MATS = 32;
+
+struct FastCtx {
+    const FShade* shade;   // LDS or global
+    const DMat* mats;      // LDS or global
+    float* pxt;            // LDS, this wave's [3][64]: i-0.5, H-j-0.5, K_px bits
+};
+
+struct FastTracer {
+    using Path = ptf::Path;
+    // Lane l prepares pixel l of the tile: jitter-free sample-plane coordinates
+    // (main.cu:62) and the pixel's RNG key.
+    static PTD void prologue(const RenderArgs& a, FastCtx& c, uint32_t base, uint32_t lane) {
+        const uint32_t idx = base + lane;
+        const uint32_t j = idx / (uint32_t)a.max_x;
+        const uint32_t i = idx - j * (uint32_t)a.max_x;
+        c.pxt[lane] = (float)(int)i - 0.5f;
+        c.pxt[64 + lane] = (float)(a.max_y - (int)j) - 0.5f;
+        c.pxt[128 + lane] = __uint_as_float(rng_hash(idx ^ a.seed_hash));
+    }
+    static PTD void start(Path& p, const RenderArgs& a, FastCtx& c, uint32_t px, uint32_t, uint32_t sample) {
+        const uint32_t kpx = __float_as_uint(c.pxt[128 + px]);
+        p.key = rng_hash(kpx + 0x9E3779B9u * (sample + 1u));
+        const float sx = c.pxt[px] + rng_u(p.key, 0u), sy = c.pxt[64 + px] + rng_u(p.key, 1u);
+        const V3 cam = v3(a.cam[0], a.cam[1], a.cam[2]);
+        const V3 pc = v3(__builtin_fmaf(a.du, sx, a.p00[0]), __builtin_fmaf(a.dv, sy, a.p00[1]), a.p00[2]);
+        p.o = cam;
+        p.d = unit_or_zero(pc - cam);
+        p.coef = v3(1.0f, 1.0f, 1.0f);
+        p.contrib = v3(0.0f, 0.0f, 0.0f);
+        p.seg = 0;
+    }
+    static PTD bool step(Path& p, const RenderArgs& a, FastCtx& c) {
+        return path_step(p, a.fprims, a.ftype, a.n_prims, c.shade, c.mats, a.n_bounces);
+    }
+    static PTD void radiance(const Path& p, float rgb[3]) { rgb[0] = p.contrib.x; rgb[1] = p.contrib.y; rgb[2] = p.contrib.z; }
+};
+
+template <bool LDS_TABLES>
+__global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, uint32_t n_tiles) {
+    __shared__ float acc[ptw::WAVES_PER_BLOCK][192];
+    __shared__ float pxt[ptw::WAVES_PER_BLOCK][192];
+    __shared__ FShade lshade[LDS_TABLES ? LDS_MAX_PRIMS : 1];
+    __shared__ DMat lmats[LDS_TABLES ? LDS_MAX_MATS : 1];
+    FastCtx ctx;
+    if (LDS_TABLES) {
+        // The whole workgroup copies the shading and material tables into LDS once.
+        const uint32_t* gs = reinterpret_cast<const uint32_t*>(a.fshade);
+        uint32_t* ls = reinterpret_cast<uint32_t*>(lshade);
+        for (uint32_t w = threadIdx.x; w < (uint32_t)a.n_prims * (sizeof(FShade) / 4); w += ptw::BLOCK) ls[w] = gs[w];
+        const uint32_t* gm = reinterpret_cast<const uint32_t*>(a.mats);
+        uint32_t* lm = reinterpret_cast<uint32_t*>(lmats);
+        for (uint32_t w = threadIdx.x; w < (uint32_t)a.n_mats * (sizeof(DMat) / 4); w += ptw::BLOCK) lm[w] = gm[w];
+        __syncthreads();
+        ctx.shade = lshade; ctx.mats = lmats;
+    } else {
+        ctx.shade = a.fshade; ctx.mats = a.mats;
+    }
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * ptw::WAVES_PER_BLOCK + wave;
+    if (tile >= n_tiles) return;
+    ctx.pxt = pxt[wave];
+    ptw::render_tile<FastTracer>(a, tile, acc[wave], ctx);
+}
+
+__global__ __launch_bounds__(256) void trace_fast_kernel(const FPrim* __restrict__ recs, const int32_t* __restrict__ tags, int n_prims,
+                                                         const FShade* __restrict__ shade, const DMat* __restrict__ mats,
+                                                         const float* __restrict__ o, const float* __restrict__ d,
+                                                         const uint32_t* __restrict__ pixel, const uint32_t* __restrict__ sample,
+                                                         int n, uint32_t seed_hash, int n_bounces, float* rgb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Path p;
+    p.key = rng_hash(rng_hash(pixel[i] ^ seed_hash) + 0x9E3779B9u * (sample[i] + 1u));
+    p.o = v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
+    p.d = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    p.coef = v3(1.0f, 1.0f, 1.0f); p.contrib = v3(0.0f, 0.0f, 0.0f); p.seg = 0;
+    while (path_step(p, recs, tags, n_prims, shade, mats, n_bounces)) {}
+    rgb[3 * i] = p.contrib.x; rgb[3 * i + 1] = p.contrib.y; rgb[3 * i + 2] = p.contrib.z;
+}
+
+}  // namespace
+
+int ptk_render_fast(const RenderArgs& a, hipStream_t s) {
+    const uint32_t npix = a.pix_end - a.pix_begin;
+    if (npix == 0) return 0;
+    const uint32_t n_tiles = (npix + 63u) / 64u;
+    const uint32_t blocks = (n_tiles + ptw::WAVES_PER_BLOCK - 1) / ptw::WAVES_PER_BLOCK;
+    if (a.n_prims <= LDS_MAX_PRIMS && a.n_mats <= LDS_MAX_MATS)
+        hipLaunchKernelGGL(render_fast_kernel<true>, dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+    else
+        hipLaunchKernelGGL(render_fast_kernel<false>, dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+    PT_CHECK(hipGetLastError());
+    return 0;
+}
+
+int ptk_trace_paths_fast(const pt_scene* sc, const float* o, const float* d, const uint32_t* pixel,
+                         const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, float* rgb, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(trace_fast_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sc->d_fprims, sc->d_ftype, sc->n_prims,
+                       sc->d_fshade, sc->d_mats, o, d, pixel, sample, n, seed_hash, n_bounces, rgb);
+    PT_CHECK(hipGetLastError());
+    return 0;
+}

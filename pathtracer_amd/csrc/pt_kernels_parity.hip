@@ -1,0 +1,152 @@
+// Kernels in the reference's operation order.  Build this file with
+// -ffp-contract=off (see Makefile): every float operation rounds on its own.
+#include "pt_parity.h"
+#include "pt_wavepool.h"
+
+using namespace ptp;
+
+namespace {
+
+struct ParityCtx {};
+
+struct ParityTracer {
+    using Path = ptp::Path;
+    static __device__ __forceinline__ void prologue(const RenderArgs&, ParityCtx&, uint32_t, uint32_t) {}
+    static __device__ __forceinline__ void start(Path& p, const RenderArgs& a, ParityCtx&, uint32_t, uint32_t pixel_index, uint32_t sample) {
+        p.key = rng_key(a.seed_hash, pixel_index, sample);
+        const int j = (int)(pixel_index / (uint32_t)a.max_x);
+        const int i = (int)(pixel_index - (uint32_t)j * (uint32_t)a.max_x);
+        camera_ray(a, i, j, p.key, &p.o, &p.d);
+        p.coef = v3(1.0f, 1.0f, 1.0f);
+        p.contrib = v3(0.0f, 0.0f, 0.0f);
+        p.seg = 0;
+    }
+    static __device__ __forceinline__ bool step(Path& p, const RenderArgs& a, ParityCtx&) {
+        return path_step(p, a.prims, a.n_prims, a.mats, a.n_bounces);
+    }
+    static __device__ __forceinline__ void radiance(const Path& p, float rgb[3]) {
+        rgb[0] = p.contrib.x; rgb[1] = p.contrib.y; rgb[2] = p.contrib.z;
+    }
+};
+
+__global__ __launch_bounds__(ptw::BLOCK) void render_parity_kernel(RenderArgs a, uint32_t n_tiles) {
+    __shared__ float acc[ptw::WAVES_PER_BLOCK][192];
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * ptw::WAVES_PER_BLOCK + wave;
+    if (tile >= n_tiles) return;
+    ParityCtx ctx;
+    ptw::render_tile<ParityTracer>(a, tile, acc[wave], ctx);
+}
+
+__device__ __forceinline__ V3 load3(const float* p, int i) { return v3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+__device__ __forceinline__ void store3(float* p, int i, V3 v) { if (p) { p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z; } }
+
+__global__ __launch_bounds__(256) void raypath_kernel(const DPrim* __restrict__ prims, int prim, const float* __restrict__ o,
+                                                      const float* __restrict__ d, int n, int filter, int32_t* dn,
+                                                      int32_t* h1, float* t1, float* p1, float* n1,
+                                                      int32_t* h2, float* t2, float* p2, float* n2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DPrim& P = prims[prim];
+    V3 ro = load3(o, i), rd = load3(d, i);
+    V3 ol = ro, dl = rd;
+    if (filter) { ol = xpoint(P.inv, ro); dl = xvec(P.inv, rd); }
+    LHit h = shape_local(P.type, ol, dl, P.bounds);
+    if (filter) eps_filter(h);
+    if (dn) dn[i] = h.n;
+    const bool v1 = h.n >= 1 && h.h1, v2 = h.n >= 2 && h.h2;
+    V3 pw = v3(0, 0, 0), nw = v3(0, 0, 0);
+    if (v1) world_point(P, ol, dl, h.t1, h.s1, &pw, &nw);
+    if (h1) h1[i] = v1 ? 1 : 0;
+    if (t1) t1[i] = v1 ? h.t1 : 0.0f;
+    store3(p1, i, pw); store3(n1, i, nw);
+    pw = v3(0, 0, 0); nw = v3(0, 0, 0);
+    if (v2) world_point(P, ol, dl, h.t2, h.s2, &pw, &nw);
+    if (h2) h2[i] = v2 ? 1 : 0;
+    if (t2) t2[i] = v2 ? h.t2 : 0.0f;
+    store3(p2, i, pw); store3(n2, i, nw);
+}
+
+__global__ __launch_bounds__(256) void nearest_kernel(const DPrim* __restrict__ prims, int n_prims, const float* __restrict__ o,
+                                                      const float* __restrict__ d, int n, int32_t* prim, float* t,
+                                                      float* pos, float* nrm, int32_t* inside) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Hit h = nearest_hit(load3(o, i), load3(d, i), prims, n_prims);
+    const bool hit = h.prim >= 0;
+    if (prim) prim[i] = h.prim;
+    if (t) t[i] = hit ? h.t : 0.0f;
+    store3(pos, i, hit ? h.pos : v3(0, 0, 0));
+    store3(nrm, i, hit ? h.nrm : v3(0, 0, 0));
+    if (inside) inside[i] = hit && h.inside ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void trace_parity_kernel(const DPrim* __restrict__ prims, int n_prims, const DMat* __restrict__ mats,
+                                                           const float* __restrict__ o, const float* __restrict__ d,
+                                                           const uint32_t* __restrict__ pixel, const uint32_t* __restrict__ sample,
+                                                           int n, uint32_t seed_hash, int n_bounces, float* rgb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Path p;
+    p.key = rng_key(seed_hash, pixel[i], sample[i]);
+    p.o = load3(o, i); p.d = load3(d, i);
+    p.coef = v3(1.0f, 1.0f, 1.0f); p.contrib = v3(0.0f, 0.0f, 0.0f); p.seg = 0;
+    while (path_step(p, prims, n_prims, mats, n_bounces)) {}
+    store3(rgb, i, p.contrib);
+}
+
+__global__ void rng_kernel(uint32_t seed_hash, uint32_t pixel, uint32_t sample, int n_slots, uint32_t* bits, float* u) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_slots) return;
+    const uint32_t key = rng_key(seed_hash, pixel, sample);
+    const uint32_t b = rng_bits(key, (uint32_t)k);
+    if (bits) bits[k] = b;
+    if (u) u[k] = rng_to_uniform(b);
+}
+
+}  // namespace
+
+int ptk_render_parity(const RenderArgs& a, hipStream_t s) {
+    const uint32_t npix = a.pix_end - a.pix_begin;
+    if (npix == 0) return 0;
+    const uint32_t n_tiles = (npix + 63u) / 64u;
+    const uint32_t blocks = (n_tiles + ptw::WAVES_PER_BLOCK - 1) / ptw::WAVES_PER_BLOCK;
+    hipLaunchKernelGGL(render_parity_kernel, dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+    PT_CHECK(hipGetLastError());
+    return 0;
+}
+
+int ptk_raypath_batch(const pt_scene* sc, int prim, const float* o, const float* d, int n, int filter,
+                      int32_t* dn, int32_t* h1, float* t1, float* p1, float* n1,
+                      int32_t* h2, float* t2, float* p2, float* n2, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(raypath_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sc->d_prims, prim, o, d, n, filter,
+                       dn, h1, t1, p1, n1, h2, t2, p2, n2);
+    PT_CHECK(hipGetLastError());
+    return 0;
+}
+
+int ptk_nearest_batch(const pt_scene* sc, const float* o, const float* d, int n, int32_t* prim, float* t,
+                      float* pos, float* nrm, int32_t* inside, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(nearest_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sc->d_prims, sc->n_prims, o, d, n,
+                       prim, t, pos, nrm, inside);
+    PT_CHECK(hipGetLastError());
+    return 0;
+}
+
+int ptk_trace_paths_parity(const pt_scene* sc, const float* o, const float* d, const uint32_t* pixel,
+                           const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, float* rgb, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(trace_parity_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sc->d_prims, sc->n_prims, sc->d_mats,
+                       o, d, pixel, sample, n, seed_hash, n_bounces, rgb);
+    PT_CHECK(hipGetLastError());
+    return 0;
+}
+
+int ptk_rng_draws(uint32_t seed_hash, uint32_t pixel, uint32_t sample, int n_slots, uint32_t* bits, float* u, hipStream_t s) {
+    if (n_slots <= 0) return 0;
+    hipLaunchKernelGGL(rng_kernel, dim3((n_slots + 63) / 64), dim3(64), 0, s, seed_hash, pixel, sample, n_slots, bits, u);
+    PT_CHECK(hipGetLastError());
+    return 0;
+}

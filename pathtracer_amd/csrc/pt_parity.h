@@ -1,0 +1,396 @@
+// Device code that follows the reference's operation order one float operation
+// at a time (shapes.h:28-361, bsdf.h:29-168, vec_math.h:10-30).  Translation
+// units that include this header are compiled with -ffp-contract=off and the
+// default correctly rounded f32 divide/sqrt, so intersection distances come out
+// bit for bit as a host restatement computes them; only sinf/cosf/expf differ
+// (device libm vs host libm).
+#pragma once
+
+#include "pt_internal.h"
+
+#define PTD __device__ __forceinline__
+
+namespace ptp {
+
+struct V3 { float x, y, z; };
+PTD V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+PTD V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PTD V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PTD V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+PTD V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+PTD V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }   // cwiseProduct
+PTD V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+// Eigen's fixed-size reductions sum as x + (y + z).
+PTD float dot(V3 a, V3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+PTD float sqn(V3 a) { return a.x * a.x + (a.y * a.y + a.z * a.z); }
+PTD V3 normalized(V3 a) {
+    float n = sqn(a);
+    if (n > 0.0f) { float s = sqrtf(n); return v3(a.x / s, a.y / s, a.z / s); }
+    return a;
+}
+// Affine3f * point and linear() * vector for a row-major [L | t] block.
+PTD V3 xvec(const float* m, V3 p) {
+    return v3(m[0] * p.x + (m[1] * p.y + m[2] * p.z), m[4] * p.x + (m[5] * p.y + m[6] * p.z),
+              m[8] * p.x + (m[9] * p.y + m[10] * p.z));
+}
+PTD V3 xpoint(const float* m, V3 p) {
+    V3 l = xvec(m, p);
+    return v3(l.x + m[3], l.y + m[7], l.z + m[11]);
+}
+
+// ---- counter RNG (stands in for curandState, main.cu:58-60) -----------------
+// bits(k) = H(K_smp ^ 0x85EBCA6B*(k+1)), K_smp = H(K_px + 0x9E3779B9*(sample+1)),
+// K_px = H(pixel ^ H(seed + 0x9E3779B9)); uniform = bits*2^-32 + 2^-33 in (0,1].
+PTD uint32_t rng_hash(uint32_t x) {
+    x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
+    return x;
+}
+PTD uint32_t rng_key(uint32_t seed_hash, uint32_t pixel, uint32_t sample) {
+    uint32_t kpx = rng_hash(pixel ^ seed_hash);
+    return rng_hash(kpx + 0x9E3779B9u * (sample + 1u));
+}
+PTD uint32_t rng_bits(uint32_t key, uint32_t slot) { return rng_hash(key ^ (0x85EBCA6Bu * (slot + 1u))); }
+PTD float rng_to_uniform(uint32_t bits) { return (float)bits * 2.3283064365386963e-10f + 1.1641532182693481e-10f; }
+PTD float rng_u(uint32_t key, uint32_t slot) { return rng_to_uniform(rng_bits(key, slot)); }
+
+// ---- local-space shape tests -------------------------------------------------
+// Surface codes let the winner's normal be rebuilt later without carrying it.
+enum { SURF_BODY = 0, SURF_DISC_POS = 1, SURF_DISC_NEG = 2 };
+
+struct LHit {
+    int n;          // RayPath::n_intersections
+    bool h1, h2;    // first/second .intersects
+    float t1, t2;   // first/second .distance
+    int s1, s2;     // surface codes
+};
+
+PTD LHit lhit_none() { LHit h; h.n = 0; h.h1 = false; h.h2 = false; h.t1 = 0.0f; h.t2 = 0.0f; h.s1 = 0; h.s2 = 0; return h; }
+
+// Plane::getRayPath (shapes.h:116-133); out of bounds or parallel => 0 hits.
+PTD LHit plane_local(V3 o, V3 d, const float* b) {
+    LHit h = lhit_none();
+    float dz = d.x * 0.0f + (d.y * 0.0f + d.z * 1.0f);
+    if (dz != 0.0f) {
+        V3 no = -1.0f * o;
+        float t = (no.x * 0.0f + (no.y * 0.0f + no.z * 1.0f)) / dz;
+        V3 pos = o + d * t;
+        if (b[0] < pos.x && b[1] < pos.y && b[2] > pos.x && b[3] > pos.y) {
+            h.n = 1; h.h1 = true; h.t1 = t;
+        }
+    }
+    return h;
+}
+
+// Cube::getRayPath (shapes.h:171-220).
+PTD LHit cube_local(V3 o, V3 d) {
+    LHit h = lhit_none();
+    float x = 1.0f / d.x, y = 1.0f / d.y, z = 1.0f / d.z;
+    float t1 = (-0.5f - o.x) * x, t2 = (0.5f - o.x) * x;
+    float t3 = (-0.5f - o.y) * y, t4 = (0.5f - o.y) * y;
+    float t5 = (-0.5f - o.z) * z, t6 = (0.5f - o.z) * z;
+    float tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+    float tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+    if (tmax < 0.0f) return h;
+    if (tmin > tmax) return h;
+    h.n = 2; h.h1 = true; h.h2 = true; h.t1 = tmin; h.t2 = tmax;
+    return h;
+}
+
+// Sphere::getRayPath (shapes.h:327-360).  (-b -+ sqrt(disc)) / (2.0*a) is a
+// double divide of float operands there; a correctly rounded f32 divide by 2a
+// gives the same float.
+PTD LHit sphere_local(V3 o, V3 d) {
+    LHit h = lhit_none();
+    float a = dot(d, d);
+    float b = 2.0f * dot(d, o);
+    float c = dot(o, o) - 0.25f;
+    float disc = b * b - 4 * a * c;
+    if (disc < 0.0f) return h;
+    float sq = sqrtf(disc);
+    float den = 2.0f * a;
+    h.n = 2; h.h1 = true; h.h2 = true;
+    h.t1 = (-b - sq) / den;
+    h.t2 = (-b + sq) / den;
+    return h;
+}
+
+// Cylinder::getIntersectionDisc (shapes.h:231-255) for disc normal (0,0,nz).
+PTD bool cyl_disc(V3 o, V3 d, float nz, float* t_out) {
+    V3 n = v3(0.0f, 0.0f, nz);
+    V3 p = n * 0.5f;
+    float dn = dot(d, n);
+    if (dn == 0.0f) return false;
+    float t = dot(p - o, n) / dn;
+    V3 pos = o + d * t;
+    if (sqrtf(sqn(pos - p)) > 0.5f) return false;
+    *t_out = t;
+    return true;
+}
+
+// Cylinder::getRayPath (shapes.h:257-318).
+PTD LHit cyl_local(V3 o, V3 d) {
+    LHit h = lhit_none();
+    float a = d.x * d.x + d.y * d.y;
+    float b = 2 * (d.x * o.x + d.y * o.y);
+    float c = (o.x * o.x + o.y * o.y) - 0.25f;
+    float disc = b * b - 4 * a * c;
+    float td1 = 0.0f, td2 = 0.0f;
+    bool d1 = cyl_disc(o, d, 1.0f, &td1);
+    bool d2 = cyl_disc(o, d, -1.0f, &td2);
+    bool c1 = false, c2 = false;
+    float tc1 = 0.0f, tc2 = 0.0f;
+    if (disc > 0.0f) {
+        float sq = sqrtf(disc);
+        float den = 2.0f * a;
+        tc1 = (-b - sq) / den;
+        float z1 = (o + d * tc1).z;
+        c1 = (-0.5f < z1 && z1 < 0.5f);
+        tc2 = (-b + sq) / den;
+        float z2 = (o + d * tc2).z;
+        c2 = (-0.5f < z2 && z2 < 0.5f);
+    }
+    if (d1 && d2) {
+        h.n = 2; h.h1 = true; h.t1 = td1; h.s1 = SURF_DISC_POS; h.h2 = true; h.t2 = td2; h.s2 = SURF_DISC_NEG;
+    } else if (d1 && disc > 0.0f) {
+        h.n = 2; h.h1 = true; h.t1 = td1; h.s1 = SURF_DISC_POS;
+        h.h2 = c1 ? c1 : c2; h.t2 = c1 ? tc1 : tc2; h.s2 = SURF_BODY;
+    } else if (d2 && disc > 0.0f) {
+        h.n = 2; h.h1 = true; h.t1 = td2; h.s1 = SURF_DISC_NEG;
+        h.h2 = c1 ? c1 : c2; h.t2 = c1 ? tc1 : tc2; h.s2 = SURF_BODY;
+    } else if (disc > 0.0f && c1 && c2) {
+        h.n = 2; h.h1 = true; h.t1 = tc1; h.s1 = SURF_BODY; h.h2 = true; h.t2 = tc2; h.s2 = SURF_BODY;
+    }
+    return h;
+}
+
+PTD LHit shape_local(int type, V3 o, V3 d, const float* bounds) {
+    switch (type) {
+        case PT_PLANE: return plane_local(o, d, bounds);
+        case PT_CUBE: return cube_local(o, d);
+        case PT_CYLINDER: return cyl_local(o, d);
+        default: return sphere_local(o, d);
+    }
+}
+
+// The epsilon filter of Shape::getIntersections (shapes.h:62-73).  The
+// reference compares against the double 0.00001; for a float distance that is
+// the same predicate as <= 1e-5f.
+PTD void eps_filter(LHit& h) {
+    const float EPS = 1e-5f;
+    if (h.n == 1 && h.t1 <= EPS) {
+        h.n = 0;
+    } else if (h.n == 2) {
+        bool a = h.t1 <= EPS, b = h.t2 <= EPS;
+        if (a && b) {
+            h.n = 0;
+        } else if (a) {
+            h.n = 1; h.h1 = h.h2; h.t1 = h.t2; h.s1 = h.s2;
+        } else if (b) {
+            h.n = 1;
+        }
+    }
+}
+
+// World position and (unflipped) normal of a local hit at distance t on the
+// given surface: the per-class code after `res.first.distance = d`
+// (shapes.h:125-129, 158-169, 205-218, 250-252, 276-279, 346-349).
+PTD void world_point(const DPrim& P, V3 o, V3 d, float t, int surf, V3* pos_w, V3* nrm_w) {
+    V3 wo = v3(P.fwd[3], P.fwd[7], P.fwd[11]);
+    V3 pos = o + d * t;
+    *pos_w = xpoint(P.fwd, pos);
+    V3 nl;
+    switch (P.type) {
+        case PT_PLANE: {
+            float s = 0.0f * d.x + (0.0f * d.y + 1.0f * d.z);
+            nl = s > 0.0f ? v3(0.0f, 0.0f, -1.0f) : v3(0.0f, 0.0f, 1.0f);
+            break;
+        }
+        case PT_CUBE: {
+            float ax = fabsf(pos.x), ay = fabsf(pos.y), az = fabsf(pos.z);
+            float m = fmaxf(ax, fmaxf(ay, az));
+            if (ax == m) nl = v3(pos.x, 0.0f, 0.0f);
+            else if (ay == m) nl = v3(0.0f, pos.y, 0.0f);
+            else nl = v3(0.0f, 0.0f, pos.z);
+            break;
+        }
+        case PT_CYLINDER: {
+            if (surf == SURF_DISC_POS) nl = v3(0.0f, 0.0f, 1.0f);
+            else if (surf == SURF_DISC_NEG) nl = v3(0.0f, 0.0f, -1.0f);
+            else nl = v3(pos.x, pos.y, 0.0f);
+            break;
+        }
+        default: nl = pos; break;
+    }
+    *nrm_w = normalized(xpoint(P.fwd, nl) - wo);
+}
+
+struct Nearest {
+    int prim;      // -1 = miss
+    float t;
+    int surf;
+};
+
+// The loop of getNearestIntersection (shapes.h:79-100): k is wave-uniform, so
+// prims[k] is fetched with scalar loads and the type switch is a scalar branch.
+PTD Nearest nearest_scan(V3 o, V3 d, const DPrim* __restrict__ prims, int n_prims) {
+    Nearest best; best.prim = -1; best.t = 0.0f; best.surf = 0;
+    for (int k = 0; k < n_prims; k++) {
+        const DPrim& P = prims[k];
+        V3 ol = xpoint(P.inv, o);
+        V3 dl = xvec(P.inv, d);
+        LHit h = shape_local(P.type, ol, dl, P.bounds);
+        eps_filter(h);
+        bool valid; float t; int surf;
+        if (h.n == 1) { valid = h.h1; t = h.t1; surf = h.s1; }
+        else if (h.n == 2) {
+            bool second = h.t2 < h.t1;
+            valid = second ? h.h2 : h.h1; t = second ? h.t2 : h.t1; surf = second ? h.s2 : h.s1;
+        } else { valid = false; t = 0.0f; surf = 0; }
+        if (valid && (best.prim < 0 || t < best.t)) { best.prim = k; best.t = t; best.surf = surf; }
+    }
+    return best;
+}
+
+struct Hit {
+    int prim;      // -1 = miss
+    float t;
+    V3 pos, nrm;
+    bool inside;
+};
+
+// getNearestIntersection including the winner's record (shapes.h:93-97).
+PTD Hit nearest_hit(V3 o, V3 d, const DPrim* __restrict__ prims, int n_prims) {
+    Nearest b = nearest_scan(o, d, prims, n_prims);
+    Hit h; h.prim = b.prim; h.t = b.t; h.pos = v3(0, 0, 0); h.nrm = v3(0, 0, 0); h.inside = false;
+    if (b.prim >= 0) {
+        const DPrim& P = prims[b.prim];
+        V3 ol = xpoint(P.inv, o);
+        V3 dl = xvec(P.inv, d);
+        world_point(P, ol, dl, b.t, b.surf, &h.pos, &h.nrm);
+        h.inside = dot(h.nrm, d) > 0.0f;
+        if (h.inside) h.nrm = -1.0f * h.nrm;
+    }
+    return h;
+}
+
+// ---- bsdf.h ---------------------------------------------------------------------
+PTD V3 reflect(V3 v, V3 n) { return v - 2 * (dot(v, n) * n); }                  // vec_math.h:19-21
+PTD V3 refract(V3 I, V3 N, float eta) {                                        // vec_math.h:23-30
+    float ndi = dot(N, I);
+    double k = 1.0 - (double)(eta * eta) * (1.0 - (double)(ndi * ndi));
+    float kf = (float)k;
+    if (kf < 0.0f) return v3(0.0f, 0.0f, 0.0f);
+    return eta * I - (eta * ndi + sqrtf(kf)) * N;
+}
+PTD V3 lerp3(V3 v0, V3 v1, float t) { return (1 - t) * v0 + t * v1; }           // vec_math.h:10-12
+PTD float lerp1(float v0, float v1, float t) { return (1 - t) * v0 + t * v1; }
+
+PTD V3 sample_hemisphere(float u1, float u2) {                                  // bsdf.h:29-36
+    float z = u1 * 2.0f - 1.0f;
+    float a = (float)((double)(u2 * 2) * 3.14159265358979323846);
+    float r = sqrtf(1.0f - z * z);
+    return v3(r * cosf(a), r * sinf(a), z);
+}
+
+PTD float fresnel_schlick(float n1, float n2, float c) {                        // bsdf.h:48-51
+    float q = (n1 - n2) / (n1 + n2);
+    float r0 = q * q;
+    float m = 1 - c;
+    float m2 = m * m;
+    float m5 = (m2 * m2) * m;
+    return r0 + (1 - r0) * m5;
+}
+
+PTD float fresnel_ratio(V3 N, V3 I, float f0, float f90, float n1, float n2) {  // bsdf.h:53-69
+    float cX = -dot(N, I);
+    if (n1 > n2) {
+        float n = n1 / n2;
+        float s2 = (float)((double)(n * n) * (1.0 - (double)(cX * cX)));
+        if (s2 > 1.0f) return f90;
+        cX = (float)sqrt(1.0 - (double)s2);
+    }
+    return lerp1(f0, f90, fresnel_schlick(n1, n2, cX));
+}
+
+struct Path {
+    V3 o, d;          // current ray
+    V3 coef;          // throughput ("coefficient", bsdf.h:76)
+    V3 contrib;       // radiance gathered so far ("contribution", bsdf.h:74)
+    uint32_t key;     // K_smp of this sample
+    int seg;          // loop index i of bsdf.h:78
+};
+
+// One iteration of the tracePath loop (bsdf.h:78-166).  Returns true when the
+// path goes on to another segment.  Draw slots of segment s are 2+6s+{0..5};
+// draws whose value cannot change the result are not evaluated.
+PTD bool path_step(Path& p, const DPrim* __restrict__ prims, int n_prims, const DMat* __restrict__ mats, int n_bounces) {
+    Hit h = nearest_hit(p.o, p.d, prims, n_prims);
+    if (h.prim < 0) return false;
+    const DMat& M = mats[prims[h.prim].material];
+    V3 emissive = v3(M.emissive[0], M.emissive[1], M.emissive[2]);
+    if (sqn(emissive) > 0.0f) p.contrib = p.contrib + emissive * p.coef;
+    if (p.seg > 0 && h.inside) {
+        V3 rc = v3(M.refractionColor[0], M.refractionColor[1], M.refractionColor[2]);
+        V3 att = (-1.0f * rc) * h.t;
+        p.coef = p.coef * v3(expf(att.x), expf(att.y), expf(att.z));
+    }
+    float f0 = M.f0, transparency = M.transparency, ior = M.IOR;
+    float p_specular = f0, p_refract = transparency;
+    if (f0 > 0.0f) {
+        p_specular = fresnel_ratio(p.d, h.nrm, f0, 1.0f, h.inside ? ior : 1.0f, !h.inside ? ior : 1.0f);
+        p_refract = transparency * (1.0f - p_specular) / (1.0f - f0);
+    }
+    uint32_t slot = 2u + 6u * (uint32_t)p.seg;
+    int mode = 3;
+    float p_ray;
+    {
+        bool need_u = p_specular > 0.0f || p_refract > 0.0f;
+        float u = need_u ? rng_u(p.key, slot) : 2.0f;
+        if (p_specular > 0.0f && u < p_specular) { mode = 1; p_ray = p_specular; }
+        else if (p_refract > 0.0f && u < p_specular + p_refract) { mode = 2; p_ray = p_refract; }
+        else { mode = 3; p_ray = 1.0f - (p_specular + p_refract); }
+    }
+    p_ray = fmaxf(p_ray, 0.001f);
+    V3 ndir;
+    if (mode == 2) {
+        V3 rd = normalized(refract(p.d, h.nrm, h.inside ? ior : 1.0f / ior));
+        float rr = M.refractionRoughness * M.refractionRoughness;
+        if (rr != 0.0f) {
+            V3 hd = normalized(h.nrm + sample_hemisphere(rng_u(p.key, slot + 3u), rng_u(p.key, slot + 4u)));
+            rd = lerp3(rd, hd, rr);
+        }
+        ndir = normalized(rd);
+    } else {
+        V3 dd = normalized(h.nrm + sample_hemisphere(rng_u(p.key, slot + 1u), rng_u(p.key, slot + 2u)));
+        if (mode == 1) {
+            V3 sd = normalized(reflect(p.d, h.nrm));
+            float sr = M.specularRoughness * M.specularRoughness;
+            sd = lerp3(sd, dd, sr);
+            ndir = normalized(sd);
+        } else {
+            ndir = dd;
+        }
+    }
+    if (mode == 1) p.coef = p.coef * v3(M.specularColor[0], M.specularColor[1], M.specularColor[2]);
+    else if (mode == 3) p.coef = p.coef * v3(M.albedo[0], M.albedo[1], M.albedo[2]);
+    p.coef = p.coef / p_ray;
+    float q = fmaxf(p.coef.x, fmaxf(p.coef.y, p.coef.z));
+    if (rng_u(p.key, slot + 5u) > q) return false;
+    p.coef = (p.coef * 1.0f) / q;
+    p.o = h.pos;
+    p.d = ndir;
+    p.seg++;
+    return p.seg <= n_bounces;
+}
+
+// Camera ray of (pixel i,j; sample) exactly as render builds it (main.cu:62-64).
+PTD void camera_ray(const RenderArgs& a, int i, int j, uint32_t key, V3* o, V3* d) {
+    float jx = rng_u(key, 0u), jy = rng_u(key, 1u);
+    float sx = (i - 0.5f + jx), sy = (a.max_y - j - 0.5f + jy);
+    V3 pc = v3((a.p00[0] + a.du * sx) + 0.0f * sy, (a.p00[1] + 0.0f * sx) + a.dv * sy, (a.p00[2] + 0.0f * sx) + 0.0f * sy);
+    V3 cam = v3(a.cam[0], a.cam[1], a.cam[2]);
+    *o = cam;
+    *d = normalized(pc - cam);
+}
+
+}  // namespace ptp
