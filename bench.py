@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the path tracer's hot path on MI355X.
+
+A step is one render of the reference's default scene at 1920x1080, 64 spp,
+depth 5, seed 0 (BASELINE.json configs[1]) through pt_render of libpt_hip.so.
+With N GPUs (one process per GPU, torch.distributed "nccl" = RCCL) the frame is
+split into N contiguous row tiles and the framebuffer is all-gathered in place
+over xGMI inside the timed step, so total work is fixed: "strong" scaling.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints one JSON line.  `roofline` prices the render kernel against the
+FP32 vector peak with ALGORITHMIC flops (the event table in
+oracle/pt_oracle.hpp, counted per config by tools/count_flops.py into
+profiles/flops_per_sample.json); `cpu_baseline` is the CPU oracle timed on this
+host on a bounded sample of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_VALU_PEAK_TFLOPS = 157.3      # 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz
+WIDTH, HEIGHT, SPP, DEPTH, SEED = 1920, 1080, 64, 5, 0
+FLOPS_KEY = "default_1920x1080_64spp_depth5_seed0"
+CPU_ROW_STEP = 4                   # cpu_baseline sample: every 4th row of the frame
+
+
+def flops_per_sample():
+    path = os.path.join(ROOT, "profiles", "flops_per_sample.json")
+    with open(path) as f:
+        return float(json.load(f)[FLOPS_KEY]["flops_per_sample"])
+
+
+def cpu_baseline(gpu_image):
+    """The CPU oracle on every CPU_ROW_STEP-th row of the same frame, all host threads of this process's share.
+    Also returns how far the GPU image is from the oracle on those rows."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_binding as ob
+    prims, n, mats, nm = ob.default_scene()
+    sc = ob.Scene(prims, n, mats, nm)
+    cfg = ob.make_config(WIDTH, HEIGHT, SPP, n_bounces=DEPTH, seed=SEED)
+    rows = np.arange(0, HEIGHT, CPU_ROW_STEP, dtype=np.int32)
+    threads = ob.default_threads()
+    t0 = time.perf_counter()
+    ref = sc.render(cfg, threads=threads, rows=rows)
+    dt = time.perf_counter() - t0
+    samples = len(rows) * WIDTH * SPP
+    base = {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": "rows j %% %d == 0 of the same 1920x1080 64-spp frame (%d rows, %.1f Msamples, %.1f s)"
+                      % (CPU_ROW_STEP, len(rows), samples / 1e6, dt)}
+    img = gpu_image.cpu().numpy()[rows].astype(np.float64)
+    ref = ref[rows].astype(np.float64)
+    parity = {"rows": int(len(rows)),
+              "rmse_rel": float(np.sqrt(((img - ref) ** 2).mean(axis=(0, 1))).max() / ref.mean()),
+              "bad_pixel_frac": float((np.abs(img - ref).max(axis=2) > 0.05).mean()),
+              "mean_rel": float((np.abs(img.mean(axis=(0, 1)) - ref.mean(axis=(0, 1))) / ref.mean(axis=(0, 1))).max())}
+    return base, parity
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--math", choices=["fast", "parity"], default="fast")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import pathtracer_amd as pt
+    from pathtracer_amd import multigpu
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible; the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    prims, n, mats, nm = pt.default_scene()
+    scene = pt.Scene(prims, n, mats, nm, device=local_rank)
+    math_mode = pt.PT_MATH_FAST if args.math == "fast" else pt.PT_MATH_PARITY
+    begin, end = multigpu.row_tile(HEIGHT, rank, world)
+    cfg = pt.make_config(WIDTH, HEIGHT, SPP, n_bounces=DEPTH, seed=SEED, row_begin=begin, row_end=end, math_mode=math_mode)
+    fb = multigpu.alloc_framebuffer(HEIGHT, WIDTH, world, device)
+    image = fb[:HEIGHT]
+
+    def step():
+        if end > begin:
+            scene.render(cfg, out=image)
+        multigpu.gather_framebuffer(fb, rank, world)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    # Kernel time: HIP events on the stream pt_render launches on (torch's current stream), around the
+    # render launch only, inside the timed region.
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        if end > begin:
+            scene.render(cfg, out=image)
+        ev[k][1].record()
+        multigpu.gather_framebuffer(fb, rank, world)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+
+    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        total_samples = WIDTH * HEIGHT * SPP
+        fps = flops_per_sample()
+        tile_samples = (end - begin) * WIDTH * SPP
+        achieved = fps * tile_samples / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Msamples/sec at 1080p 64spp",
+            "value": total_samples * args.steps / elapsed / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "reference default scene (main.cu:73-195), 1920x1080, 64 spp, depth 5, seed 0",
+                       "math_mode": args.math, "partition": "%d contiguous row tiles + in-place all-gather" % world,
+                       "flops_per_sample": fps},
+            "roofline": {"bound": "valu_fp32", "kernel": "render_fast_kernel" if args.math == "fast" else "render_parity_kernel",
+                         "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": None,
+                         "kernel_ms": kernel_ms, "kernel_msamples_per_s": tile_samples / kernel_ms / 1e3},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"], out["parity_vs_oracle"] = cpu_baseline(image)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -291,7 +291,17 @@ void oracle_camera_rays(const oracle_config* cfg, const int* pi, const int* pj, 
 // render (main.cu:30-69) over rows [row_begin,row_end), multithreaded over rows.
 // fb is the full-image AoS buffer fb[(j*max_x+i)*3+c]; only the tile's rows are
 // written.  stats may be null; it is filled only by the counting build.
+// `rows` (may be null) lists the rows to render; when null, rows
+// [row_begin,row_end) are rendered.
+int oracle_render_rows(void* scene, const oracle_config* cfg, const int* rows, int n_rows, float* fb, int n_threads,
+                       oracle_stats* stats);
+
 int oracle_render(void* scene, const oracle_config* cfg, float* fb, int n_threads, oracle_stats* stats) {
+    return oracle_render_rows(scene, cfg, nullptr, 0, fb, n_threads, stats);
+}
+
+int oracle_render_rows(void* scene, const oracle_config* cfg, const int* rows, int n_rows, float* fb, int n_threads,
+                       oracle_stats* stats) {
     Scene* sc = static_cast<Scene*>(scene);
     config_t config;
     config.camera_pos = vec3(cfg->camera_pos[0], cfg->camera_pos[1], cfg->camera_pos[2]);
@@ -300,6 +310,10 @@ int oracle_render(void* scene, const oracle_config* cfg, float* fb, int n_thread
     if (n_threads < 1) n_threads = 1;
     int row_begin = cfg->row_begin, row_end = cfg->row_end;
     if (row_begin < 0 || row_end > cfg->max_y || row_begin > row_end) return -1;
+    if (rows) {
+        for (int k = 0; k < n_rows; k++) if (rows[k] < 0 || rows[k] >= cfg->max_y) return -1;
+        row_begin = 0; row_end = n_rows;
+    }
     std::atomic<int> next_row(row_begin);
     std::vector<Stats> per_thread(n_threads);
     auto worker = [&](int tid) {
@@ -311,6 +325,7 @@ int oracle_render(void* scene, const oracle_config* cfg, float* fb, int n_thread
         for (;;) {
             int j = next_row.fetch_add(1);
             if (j >= row_end) break;
+            if (rows) j = rows[j];
             for (int i = 0; i < config.max_x; i++) {
                 vec3 c = renderPixel(config, sc->ptrs.data(), (int)sc->ptrs.size(), i, j,
                                      cfg->n_samples, cfg->n_bounces, cfg->seed);

@@ -75,6 +75,7 @@ def lib(count=False):
         L.oracle_focal_length.restype = C.c_float
         L.oracle_focal_length.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float]
         L.oracle_render.argtypes = [C.c_void_p, C.POINTER(Config), C.c_void_p, C.c_int, C.POINTER(Stats)]
+        L.oracle_render_rows.argtypes = [C.c_void_p, C.POINTER(Config), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(Stats)]
         L.oracle_ppm.restype = C.c_long
         L.oracle_ppm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_long]
         _libs[name] = L
@@ -83,6 +84,17 @@ def lib(count=False):
 
 def _fp(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def default_threads():
+    """Host threads for the oracle: the process's CPU share (OMP_NUM_THREADS on the GPU box), not the machine's CPU count."""
+    env = os.environ.get("OMP_NUM_THREADS")
+    if env and env.isdigit() and int(env) > 0:
+        return int(env)
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return os.cpu_count() or 1
 
 
 def default_scene():
@@ -127,12 +139,16 @@ class Scene:
     def __del__(self):
         self.close()
 
-    def render(self, cfg, threads=None, want_stats=False):
-        """Returns fb[H,W,3] float32 (row 0 = image bottom); rows outside the tile stay 0."""
+    def render(self, cfg, threads=None, want_stats=False, rows=None):
+        """Returns fb[H,W,3] float32 (row 0 = image bottom); rows outside the tile (or not in `rows`) stay 0."""
         fb = np.zeros((cfg.max_y, cfg.max_x, 3), dtype=np.float32)
         st = Stats()
-        threads = threads or os.cpu_count() or 1
-        rc = self.L.oracle_render(self.h, C.byref(cfg), _fp(fb), int(threads), C.byref(st))
+        threads = threads or default_threads()
+        if rows is not None:
+            rows = np.ascontiguousarray(rows, np.int32)
+            rc = self.L.oracle_render_rows(self.h, C.byref(cfg), _fp(rows), int(rows.shape[0]), _fp(fb), int(threads), C.byref(st))
+        else:
+            rc = self.L.oracle_render(self.h, C.byref(cfg), _fp(fb), int(threads), C.byref(st))
         if rc != 0:
             raise RuntimeError("oracle_render rc=%d" % rc)
         return (fb, st) if want_stats else fb

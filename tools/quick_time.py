@@ -1,5 +1,6 @@
 """Quick timing of pt_render on the GPU box (development aid)."""
-import sys, time
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import pathtracer_amd as pt
 
