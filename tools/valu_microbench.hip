@@ -1,0 +1,202 @@
+// Instruction-throughput microbenchmark for gfx950 (development aid, not part of
+// the library).  For each VALU instruction kind it runs a long unrolled stream
+// of that instruction on W waves per SIMD (W = 1, 2, 4, 8) and reports shader
+// cycles per wave-instruction per SIMD, from s_memtime stamps inside the kernel.
+//
+//   hipcc --offload-arch=gfx950 -O2 tools/valu_microbench.hip -o /tmp/valu_mb && /tmp/valu_mb
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+
+#define REP8(x) x x x x x x x x
+#define REP64(x) REP8(REP8(x))
+
+constexpr int ITERS = 1000;         // 1000 * 64 = 64000 instructions per wave
+
+#define KERNEL(name, body, pre)                                                                   \
+    __global__ __launch_bounds__(256) void k_##name(unsigned long long* out, float seed) {        \
+        float a0 = seed + threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f;               \
+        float a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;                         \
+        float b = seed * 0.5f + 1.0f, c = seed + 0.25f;                                           \
+        unsigned long long m = 0; (void)m;                                                        \
+        pre;                                                                                      \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+        for (int it = 0; it < ITERS; it++) {                                                      \
+            REP8(body)                                                                            \
+        }                                                                                         \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+        float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                                          \
+        if (s == 12345.678f) out[0] = 1;                                                          \
+        if ((threadIdx.x & 63) == 0) out[1 + blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;      \
+    }
+
+// eight independent accumulators per group of 8 instructions
+#define OP3(ins) \
+    asm volatile(ins " %0, %0, %8, %9\n\t" ins " %1, %1, %8, %9\n\t" ins " %2, %2, %8, %9\n\t" ins " %3, %3, %8, %9\n\t" \
+                 ins " %4, %4, %8, %9\n\t" ins " %5, %5, %8, %9\n\t" ins " %6, %6, %8, %9\n\t" ins " %7, %7, %8, %9"     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+#define OP2(ins) \
+    asm volatile(ins " %0, %0, %8\n\t" ins " %1, %1, %8\n\t" ins " %2, %2, %8\n\t" ins " %3, %3, %8\n\t" \
+                 ins " %4, %4, %8\n\t" ins " %5, %5, %8\n\t" ins " %6, %6, %8\n\t" ins " %7, %7, %8"     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+#define OP1(ins) \
+    asm volatile(ins " %0, %0\n\t" ins " %1, %1\n\t" ins " %2, %2\n\t" ins " %3, %3\n\t" \
+                 ins " %4, %4\n\t" ins " %5, %5\n\t" ins " %6, %6\n\t" ins " %7, %7"     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+// compare into vcc (VOPC) and into an SGPR pair (VOP3)
+#define OPCMP_VCC \
+    asm volatile("v_cmp_lt_f32 vcc, %0, %8\n\tv_cmp_lt_f32 vcc, %1, %8\n\tv_cmp_lt_f32 vcc, %2, %8\n\tv_cmp_lt_f32 vcc, %3, %8\n\t" \
+                 "v_cmp_lt_f32 vcc, %4, %8\n\tv_cmp_lt_f32 vcc, %5, %8\n\tv_cmp_lt_f32 vcc, %6, %8\n\tv_cmp_lt_f32 vcc, %7, %8"     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");
+#define OPCMP_SGPR \
+    asm volatile("v_cmp_lt_f32_e64 %8, %0, %9\n\tv_cmp_lt_f32_e64 %8, %1, %9\n\tv_cmp_lt_f32_e64 %8, %2, %9\n\tv_cmp_lt_f32_e64 %8, %3, %9\n\t" \
+                 "v_cmp_lt_f32_e64 %8, %4, %9\n\tv_cmp_lt_f32_e64 %8, %5, %9\n\tv_cmp_lt_f32_e64 %8, %6, %9\n\tv_cmp_lt_f32_e64 %8, %7, %9"     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=s"(m) : "v"(b));
+#define OPCNDMASK \
+    asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n\tv_cndmask_b32 %1, %1, %8, vcc\n\tv_cndmask_b32 %2, %2, %8, vcc\n\tv_cndmask_b32 %3, %3, %8, vcc\n\t" \
+                 "v_cndmask_b32 %4, %4, %8, vcc\n\tv_cndmask_b32 %5, %5, %8, vcc\n\tv_cndmask_b32 %6, %6, %8, vcc\n\tv_cndmask_b32 %7, %7, %8, vcc"     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");
+#define OPSALU \
+    asm volatile("s_and_b64 %0, %0, exec\n\ts_or_b64 %0, %0, vcc\n\ts_and_b64 %0, %0, exec\n\ts_or_b64 %0, %0, vcc\n\t" \
+                 "s_and_b64 %0, %0, exec\n\ts_or_b64 %0, %0, vcc\n\ts_and_b64 %0, %0, exec\n\ts_or_b64 %0, %0, vcc" : "+s"(m) :: "scc");
+// mixed: 6 VALU fma + 2 SALU per group (do SALU instructions steal VALU issue slots?)
+#define OPMIX \
+    asm volatile("v_fma_f32 %0, %0, %8, %9\n\ts_and_b64 %10, %10, exec\n\tv_fma_f32 %1, %1, %8, %9\n\tv_fma_f32 %2, %2, %8, %9\n\t" \
+                 "v_fma_f32 %3, %3, %8, %9\n\ts_or_b64 %10, %10, vcc\n\tv_fma_f32 %4, %4, %8, %9\n\tv_fma_f32 %5, %5, %8, %9"     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(m) : "scc");
+// packed f32: operands are 64-bit register pairs
+#define OPPK(ins) \
+    asm volatile(ins " %0, %0, %4, %5\n\t" ins " %1, %1, %4, %5\n\t" ins " %2, %2, %4, %5\n\t" ins " %3, %3, %4, %5\n\t" \
+                 ins " %0, %0, %4, %5\n\t" ins " %1, %1, %4, %5\n\t" ins " %2, %2, %4, %5\n\t" ins " %3, %3, %4, %5"     \
+                 : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb), "v"(pc));
+
+
+// VALU with one SGPR source operand (the render kernels read primitive records from SGPRs)
+#define OP3S(ins) \
+    asm volatile(ins " %0, %0, %8, %9\n\t" ins " %1, %1, %8, %9\n\t" ins " %2, %2, %8, %9\n\t" ins " %3, %3, %8, %9\n\t" \
+                 ins " %4, %4, %8, %9\n\t" ins " %5, %5, %8, %9\n\t" ins " %6, %6, %8, %9\n\t" ins " %7, %7, %8, %9"     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(b), "v"(c));
+#define OP2S(ins) \
+    asm volatile(ins " %0, %8, %0\n\t" ins " %1, %8, %1\n\t" ins " %2, %8, %2\n\t" ins " %3, %8, %3\n\t" \
+                 ins " %4, %8, %4\n\t" ins " %5, %8, %5\n\t" ins " %6, %8, %6\n\t" ins " %7, %8, %7"     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(b));
+#define OPCNDMASK_S \
+    asm volatile("v_cndmask_b32_e64 %0, %0, %8, %9\n\tv_cndmask_b32_e64 %1, %1, %8, %9\n\tv_cndmask_b32_e64 %2, %2, %8, %9\n\tv_cndmask_b32_e64 %3, %3, %8, %9\n\t" \
+                 "v_cndmask_b32_e64 %4, %4, %8, %9\n\tv_cndmask_b32_e64 %5, %5, %8, %9\n\tv_cndmask_b32_e64 %6, %6, %8, %9\n\tv_cndmask_b32_e64 %7, %7, %8, %9"     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "s"(m));
+// cndmask whose two value operands differ from the destination (no read-modify-write of the accumulator)
+#define OPCNDMASK_2 \
+    asm volatile("v_cndmask_b32 %0, %8, %9, vcc\n\tv_cndmask_b32 %1, %8, %9, vcc\n\tv_cndmask_b32 %2, %8, %9, vcc\n\tv_cndmask_b32 %3, %8, %9, vcc\n\t" \
+                 "v_cndmask_b32 %4, %8, %9, vcc\n\tv_cndmask_b32 %5, %8, %9, vcc\n\tv_cndmask_b32 %6, %8, %9, vcc\n\tv_cndmask_b32 %7, %8, %9, vcc"     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+// the select pattern of the primitive loop: compare then two selects on its mask
+#define OPCMPSEL \
+    asm volatile("v_cmp_lt_f32 vcc, %0, %8\n\tv_cndmask_b32 %1, %1, %8, vcc\n\tv_cndmask_b32 %2, %2, %9, vcc\n\tv_cmp_lt_f32 vcc, %3, %8\n\t" \
+                 "v_cndmask_b32 %4, %4, %8, vcc\n\tv_cndmask_b32 %5, %5, %9, vcc\n\tv_fma_f32 %6, %6, %8, %9\n\tv_fma_f32 %7, %7, %8, %9"     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+#define PKPRE float2v p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pb = {b, b}, pc = {c, c};
+
+KERNEL(fma, OP3("v_fma_f32"), )
+KERNEL(mul, OP2("v_mul_f32"), )
+KERNEL(add, OP2("v_add_f32"), )
+KERNEL(max, OP2("v_max_f32"), )
+KERNEL(max3, OP3("v_max3_f32"), )
+KERNEL(med3, OP3("v_med3_f32"), )
+KERNEL(cmp_vcc, OPCMP_VCC, )
+KERNEL(cmp_sgpr, OPCMP_SGPR, )
+KERNEL(cndmask, OPCNDMASK, )
+KERNEL(mul_lo_u32, OP2("v_mul_lo_u32"), )
+KERNEL(mul_hi_u32, OP2("v_mul_hi_u32"), )
+KERNEL(mad_u32_u24, OP3("v_mad_u32_u24"), )
+KERNEL(mul_u32_u24, OP2("v_mul_u32_u24"), )
+KERNEL(xor, OP2("v_xor_b32"), )
+KERNEL(lshrrev, OP2("v_lshrrev_b32"), )
+KERNEL(add_u32, OP2("v_add_u32"), )
+KERNEL(xad_u32, OP3("v_xad_u32"), )
+KERNEL(lshl_add_u32, OP3("v_lshl_add_u32"), )
+KERNEL(alignbit, OP3("v_alignbit_b32"), )
+KERNEL(rcp, OP1("v_rcp_f32"), )
+KERNEL(rsq, OP1("v_rsq_f32"), )
+KERNEL(sqrt, OP1("v_sqrt_f32"), )
+KERNEL(sin, OP1("v_sin_f32"), )
+KERNEL(exp, OP1("v_exp_f32"), )
+KERNEL(cvt_f32_u32, OP1("v_cvt_f32_u32"), )
+KERNEL(fma_sgpr, OP3S("v_fma_f32"), )
+KERNEL(mul_sgpr, OP2S("v_mul_f32"), )
+KERNEL(fmac, OP2("v_fmac_f32"), )
+KERNEL(min, OP2("v_min_f32"), )
+KERNEL(sub, OP2("v_sub_f32"), )
+KERNEL(mov, OP1("v_mov_b32"), )
+KERNEL(and, OP2("v_and_b32"), )
+KERNEL(bfe_u32, OP3("v_bfe_u32"), )
+KERNEL(cndmask_sgpr, OPCNDMASK_S, )
+KERNEL(cndmask_2src, OPCNDMASK_2, )
+KERNEL(cmp_sel_mix, OPCMPSEL, )
+KERNEL(salu, OPSALU, )
+KERNEL(mix_fma_salu, OPMIX, )
+
+__global__ __launch_bounds__(256) void k_pk_fma(unsigned long long* out, float seed) {
+    float a0 = seed + threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    float b = seed * 0.5f + 1.0f, c = seed + 0.25f;
+    PKPRE
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int it = 0; it < ITERS; it++) { REP8(OPPK("v_pk_fma_f32")) }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float s = p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
+    if (s == 12345.678f) out[0] = 1;
+    if ((threadIdx.x & 63) == 0) out[1 + blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+typedef void (*kern_t)(unsigned long long*, float);
+struct Entry { const char* name; kern_t k; };
+
+int main() {
+    std::vector<Entry> ks = {
+#define E(n) {#n, k_##n}
+        E(fma), E(mul), E(add), E(max), E(max3), E(med3), E(cmp_vcc), E(cmp_sgpr), E(cndmask), E(mul_lo_u32), E(mul_hi_u32),
+        E(mad_u32_u24), E(mul_u32_u24), E(xor), E(lshrrev), E(add_u32), E(xad_u32), E(lshl_add_u32), E(alignbit),
+        E(rcp), E(rsq), E(sqrt), E(sin), E(exp), E(cvt_f32_u32), E(pk_fma), E(fma_sgpr), E(mul_sgpr), E(fmac), E(min), E(sub), E(mov), E(and), E(bfe_u32), E(cndmask_sgpr), E(cndmask_2src), E(cmp_sel_mix), E(salu), E(mix_fma_salu)};
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount;
+    printf("device %s, %d CUs\n", prop.name, cus);
+    unsigned long long* d;
+    const int max_blocks = cus * 8;
+    hipMalloc(&d, sizeof(unsigned long long) * (1 + max_blocks * 4));
+    std::vector<unsigned long long> h(1 + max_blocks * 4);
+    printf("%-16s %10s %10s %10s %10s   (shader cycles per wave-instruction per SIMD; 256-thread blocks, W blocks per CU)\n", "instruction", "W=1", "W=2", "W=4", "W=8");
+    const double n_instr = (double)ITERS * 64.0;
+    for (auto& e : ks) {
+        printf("%-16s", e.name);
+        float wall8 = 0;
+        for (int w : {1, 2, 4, 8}) {
+            const int blocks = cus * w;
+            hipMemset(d, 0, sizeof(unsigned long long) * (1 + max_blocks * 4));
+            hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, d, 1.0f);   // warm-up
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, d, 1.0f);
+            hipEventRecord(e1, 0);
+            hipDeviceSynchronize();
+            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+            if (w == 8) wall8 = ms;
+            hipMemcpy(h.data(), d, sizeof(unsigned long long) * (1 + blocks * 4), hipMemcpyDeviceToHost);
+            std::vector<unsigned long long> v(h.begin() + 1, h.begin() + 1 + blocks * 4);
+            std::sort(v.begin(), v.end());
+            const double med = (double)v[v.size() / 2];
+            // a wave's stream took `med` cycles while W waves shared its SIMD
+            printf(" %10.2f", med / n_instr / w);
+        }
+        // wall-clock cross-check at W=8: wave-instructions per ns per SIMD
+        printf("   | W=8 wall %.1f us -> %.3f wave-instr/ns/SIMD\n", wall8 * 1e3, n_instr * 8.0 / (wall8 * 1e6));
+    }
+    hipFree(d);
+    return 0;
+}
