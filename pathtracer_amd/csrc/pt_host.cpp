@@ -129,26 +129,48 @@ float host_uniform(uint32_t key, uint32_t slot) {
 
 float len3(float x, float y, float z) { return sqrtf(x * x + y * y + z * z); }
 
-// Tag, intersection record and shading record of the fast kernels for one shape.
-void bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, FPrim* fp, FShade* fs, int32_t* ftype) {
-    std::memset(fp, 0, sizeof(*fp));
+// Kind, intersection record and shading record of the fast kernels for one
+// shape.  Returns the record length in floats.
+int bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, float* rec, FShade* fs, int32_t* ftype) {
     std::memset(fs, 0, sizeof(*fs));
     fs->type = p.type; fs->material = p.material;
-    // unit columns of L
-    float col[3][3], ncol[3][3];
+    float col[3][3], ncol[3][3];   // columns of L and their unit vectors
     for (int j = 0; j < 3; j++) {
         for (int i = 0; i < 3; i++) col[j][i] = fwd.m[i][j];
         const float l = len3(col[j][0], col[j][1], col[j][2]);
         for (int i = 0; i < 3; i++) ncol[j][i] = l > 0.0f ? col[j][i] / l : col[j][i];
     }
+    auto put_inv = [&]() { for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) rec[i * 4 + j] = inv.m[i][j]; };
     switch (p.type) {
         case PT_PLANE: {
-            *ftype = FP_PLANE;
-            for (int j = 0; j < 4; j++) { fp->r[j] = inv.m[2][j]; fp->r[4 + j] = inv.m[0][j]; fp->r[8 + j] = inv.m[1][j]; fp->r[12 + j] = p.bounds[j]; }
             for (int i = 0; i < 3; i++) fs->a[i] = ncol[2][i];
-            break;
+            // Fold the bounds into rows x and y: x' = (x - cx)/hx, so xMin < x < xMax <=> |x'| < 1.
+            // Bounds beyond +-1e30 count as unbounded; a half-bounded axis keeps the explicit test.
+            const double INF = 1e30;
+            double sc[2], cc[2];
+            bool foldable = true;
+            for (int ax = 0; ax < 2; ax++) {
+                const double lo = p.bounds[ax], hi = p.bounds[2 + ax];
+                const bool lo_inf = lo < -INF, hi_inf = hi > INF;
+                if (lo_inf && hi_inf) { sc[ax] = 0.0; cc[ax] = 0.0; }
+                else if (!lo_inf && !hi_inf && hi > lo) { sc[ax] = 2.0 / (hi - lo); cc[ax] = 0.5 * (hi + lo); }
+                else foldable = false;
+            }
+            for (int j = 0; j < 4; j++) rec[j] = inv.m[2][j];
+            if (foldable) {
+                *ftype = FP_PLANE;
+                for (int ax = 0; ax < 2; ax++) {
+                    for (int j = 0; j < 3; j++) rec[4 + 4 * ax + j] = (float)(inv.m[ax][j] * sc[ax]);
+                    rec[4 + 4 * ax + 3] = (float)((inv.m[ax][3] - cc[ax]) * sc[ax]);
+                }
+                return 12;
+            }
+            *ftype = FP_PLANE_GEN;
+            for (int j = 0; j < 4; j++) { rec[4 + j] = inv.m[0][j]; rec[8 + j] = inv.m[1][j]; rec[12 + j] = p.bounds[j]; }
+            return 16;
         }
         case PT_SPHERE: {
+            fs->a[0] = fwd.m[0][3]; fs->a[1] = fwd.m[1][3]; fs->a[2] = fwd.m[2][3];
             // L = s * R (orthogonal columns of equal length): the local quadratic
             // equals the world one with centre t and radius s/2.
             const float l0 = len3(col[0][0], col[0][1], col[0][2]), l1 = len3(col[1][0], col[1][1], col[1][2]),
@@ -159,28 +181,27 @@ void bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, FPrim* fp, FSha
                                  fabsf(dotc(0, 1)) <= tol && fabsf(dotc(0, 2)) <= tol && fabsf(dotc(1, 2)) <= tol;
             if (uniform) {
                 *ftype = FP_SPHERE_WS;
-                fp->r[0] = fwd.m[0][3]; fp->r[1] = fwd.m[1][3]; fp->r[2] = fwd.m[2][3];
+                rec[0] = fwd.m[0][3]; rec[1] = fwd.m[1][3]; rec[2] = fwd.m[2][3];
                 const float rad = 0.5f * l0;
-                fp->r[3] = rad * rad;
-            } else {
-                *ftype = FP_SPHERE;
-                for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) fp->r[i * 4 + j] = inv.m[i][j];
+                rec[3] = rad * rad;
+                return 4;
             }
-            fs->a[0] = fwd.m[0][3]; fs->a[1] = fwd.m[1][3]; fs->a[2] = fwd.m[2][3];
-            break;
+            *ftype = FP_SPHERE;
+            put_inv();
+            return 12;
         }
         case PT_CUBE: {
             *ftype = FP_CUBE;
-            for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) fp->r[i * 4 + j] = inv.m[i][j];
+            put_inv();
             for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) fs->a[j * 3 + i] = ncol[j][i];
-            break;
+            return 12;
         }
         default: {   // PT_CYLINDER
             *ftype = FP_CYLINDER;
-            for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) fp->r[i * 4 + j] = inv.m[i][j];
+            put_inv();
             for (int i = 0; i < 3; i++) { fs->a[i] = col[0][i]; fs->a[3 + i] = col[1][i]; fs->a[6 + i] = ncol[2][i]; }
             for (int j = 0; j < 4; j++) { fs->a[9 + j] = inv.m[0][j]; fs->a[13 + j] = inv.m[1][j]; }
-            break;
+            return 12;
         }
     }
 }
@@ -270,9 +291,9 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
     }
     PT_CHECK(hipSetDevice(device));
     std::vector<DPrim> dp(n_prims);
-    std::vector<FPrim> fp(n_prims);
     std::vector<FShade> fs(n_prims);
-    std::vector<int32_t> ft(n_prims);
+    std::vector<float> fdata;
+    std::vector<FRun> runs;
     for (int k = 0; k < n_prims; k++) {
         const Aff fwd = aff_load(prims[k].transform);
         const Aff inv = aff_inverse(fwd);
@@ -280,8 +301,18 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
         aff_store(fwd, dp[k].fwd);
         for (int j = 0; j < 4; j++) dp[k].bounds[j] = prims[k].bounds[j];
         dp[k].type = prims[k].type; dp[k].material = prims[k].material; dp[k].pad[0] = dp[k].pad[1] = 0;
-        bake_fast(prims[k], fwd, inv, &fp[k], &fs[k], &ft[k]);
+        float rec[16];
+        int32_t ft = 0;
+        const int len = bake_fast(prims[k], fwd, inv, rec, &fs[k], &ft);
+        if (runs.empty() || runs.back().type != ft) {
+            while (fdata.size() % 16) fdata.push_back(0.0f);   // runs start on a 64-byte line
+            FRun r; r.type = ft; r.first = k; r.count = 0; r.offset = (int32_t)fdata.size();
+            runs.push_back(r);
+        }
+        runs.back().count++;
+        fdata.insert(fdata.end(), rec, rec + len);
     }
+    for (int pad = 0; pad < 16; pad++) fdata.push_back(0.0f);   // scalar loads may read past the last record
     std::vector<DMat> dm(n_mats);
     for (int i = 0; i < n_mats; i++) {
         std::memset(&dm[i], 0, sizeof(DMat));
@@ -298,9 +329,10 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
     if (e != hipSuccess) { pt_scene_free(sc); return pt_set_error((int)e, "scene upload " #dst, __FILE__, __LINE__); }
     UP(d_prims, dp, DPrim)
     UP(d_mats, dm, DMat)
-    UP(d_fprims, fp, FPrim)
+    UP(d_fdata, fdata, float)
+    UP(d_runs, runs, FRun)
     UP(d_fshade, fs, FShade)
-    UP(d_ftype, ft, int32_t)
+    sc->n_runs = (int)runs.size();
 #undef UP
     *out = sc;
     return 0;
@@ -311,9 +343,9 @@ int pt_scene_free(pt_scene* sc) {
     (void)hipSetDevice(sc->device);
     if (sc->d_prims) (void)hipFree(sc->d_prims);
     if (sc->d_mats) (void)hipFree(sc->d_mats);
-    if (sc->d_fprims) (void)hipFree(sc->d_fprims);
+    if (sc->d_fdata) (void)hipFree(sc->d_fdata);
+    if (sc->d_runs) (void)hipFree(sc->d_runs);
     if (sc->d_fshade) (void)hipFree(sc->d_fshade);
-    if (sc->d_ftype) (void)hipFree(sc->d_ftype);
     delete sc;
     return 0;
 }
@@ -354,7 +386,7 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     a.fb_layout = cfg->fb_layout;
     a.n_prims = sc->n_prims; a.n_mats = sc->n_mats;
     a.prims = sc->d_prims; a.mats = sc->d_mats;
-    a.fprims = sc->d_fprims; a.fshade = sc->d_fshade; a.ftype = sc->d_ftype;
+    a.fdata = sc->d_fdata; a.runs = sc->d_runs; a.n_runs = sc->n_runs; a.fshade = sc->d_fshade;
     a.fb = d_fb;
     if (cfg->math_mode == PT_MATH_PARITY) return ptk_render_parity(a, (hipStream_t)stream);
     if (cfg->math_mode == PT_MATH_FAST) return ptk_render_fast(a, (hipStream_t)stream);

@@ -34,12 +34,20 @@ struct DMat {
     float pad[2];
 };
 
-// Intersection record of the fast kernels: 16 floats, one s_load_dwordx16.
-//   plane : r0 = row z of T^-1 (local o.z, d.z), r1 = row x, r2 = row y, r3 = bounds
-//   sphere (uniform scale): r0 = centre.xyz, radius^2 ; rest unused
-//   sphere (general), cube, cylinder: r0..r2 = rows of T^-1
-struct FPrim {
-    float r[16];
+// Intersection data of the fast kernels: one float array, cut into RUNS of
+// consecutive primitives of the same kind so that the primitive loop is a tight
+// per-kind loop in the scene's own order (ties keep the lowest index, as in
+// shapes.h:93).  Record layouts (floats):
+//   FP_PLANE (12)     : row z of T^-1 (4) | row x scaled (4) | row y scaled (4)
+//                       — the scaled rows map the bounds to |x'| < 1, |y'| < 1
+//   FP_PLANE_GEN (16) : rows z, x, y of T^-1 (12) | xMin, yMin, xMax, yMax
+//   FP_SPHERE_WS (4)  : centre.xyz, radius^2   (L = s*R: tested in world space)
+//   FP_SPHERE, FP_CUBE, FP_CYLINDER (12): rows of T^-1
+struct FRun {
+    int32_t type;     // FP_*
+    int32_t first;    // index of the run's first primitive in the scene
+    int32_t count;
+    int32_t offset;   // of the run's first record in the float array
 };
 // Shading record of the fast kernels, fetched per lane for the winning primitive.
 //   plane   : a[0..2] = unit world normal (third column of L)
@@ -54,7 +62,7 @@ struct FShade {
     int32_t pad[2];
 };
 
-enum { FP_PLANE = 0, FP_CUBE = 1, FP_CYLINDER = 2, FP_SPHERE = 3, FP_SPHERE_WS = 4 };
+enum { FP_PLANE = 0, FP_CUBE = 1, FP_CYLINDER = 2, FP_SPHERE = 3, FP_SPHERE_WS = 4, FP_PLANE_GEN = 5 };
 
 struct pt_scene {
     int device;
@@ -62,9 +70,10 @@ struct pt_scene {
     int n_mats;
     DPrim* d_prims;
     DMat* d_mats;
-    FPrim* d_fprims;
+    float* d_fdata;        // fast-kernel intersection records
+    FRun* d_runs;
+    int n_runs;
     FShade* d_fshade;
-    int32_t* d_ftype;      // fast-kernel tag per primitive (FP_*)
 };
 
 // Camera constants computed on the host in the reference's operation order
@@ -81,9 +90,10 @@ struct RenderArgs {
     int32_t n_prims, n_mats;
     const DPrim* prims;
     const DMat* mats;
-    const FPrim* fprims;
+    const float* fdata;
+    const FRun* runs;
+    int32_t n_runs;
     const FShade* fshade;
-    const int32_t* ftype;
     float* fb;
 };
 

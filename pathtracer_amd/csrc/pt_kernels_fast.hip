@@ -2,9 +2,9 @@
 //
 // Same algorithm, same counter-RNG streams and same branch structure as the
 // parity-order kernels, but written for VALU throughput:
-//  * the primitive loop reads 16-float intersection records through scalar
-//    loads (k is wave-uniform), so the records live in SGPRs and cost no VGPRs
-//    and no LDS bandwidth;
+//  * the primitive loop walks runs of same-kind primitives and reads their
+//    records through scalar loads (every index is wave-uniform), so the records
+//    live in SGPRs and cost no VGPRs and no LDS bandwidth;
 //  * planes are tested as t = -(n.o + w) / (n.d) with the bounds check on two
 //    more rows of T^-1; uniformly scaled spheres are tested in world space;
 //    cubes keep the slab test and remember the face axis so the normal needs no
@@ -58,65 +58,85 @@ constexpr float EPS = 1e-5f;   // SMALL_NUMBER (vec_math.h:7) as the float predi
 
 struct Best {
     float t;      // +inf = miss
-    int prim;
-    int code;     // cube: face axis 0..2, bit 2 = exit face; cylinder: surface 0 body, 1 disc +z, 2 disc -z
+    int id;       // (primitive index << 3) | code; code: cube = face axis 0..2 (+4 = exit face),
+                  // cylinder = surface 0 body, 1 disc +z, 2 disc -z
 };
 
-// One primitive against one ray.  `R` is the wave-uniform record.
-PTD void test_plane(const float* R, V3 o, V3 d, int k, Best& b) {
+// Every test below ends the same way: the candidate replaces the best hit when
+// EPS < t < best.t (plus its own validity mask).  Strict '<' keeps the lowest
+// primitive index on ties, as getNearestIntersection does (shapes.h:93).
+
+// Plane with the bounds folded into rows x', y' (record: z row | x' row | y' row).
+PTD void test_plane(const float* R, V3 o, V3 d, int id, Best& b) {
     const float oz = row_point(R, o);
     const float dz = row_vec(R, d);
     const float t = -oz * rcp(dz);                 // dz == 0 gives inf/nan: every compare below fails
     const V3 p = madd(d, t, o);
     const float xl = row_point(R + 4, p), yl = row_point(R + 8, p);
-    const bool ok = (t > EPS) & (t < b.t) & (xl > R[12]) & (yl > R[13]) & (xl < R[14]) & (yl < R[15]);
-    if (ok) { b.t = t; b.prim = k; b.code = 0; }
+    const bool ok = (t > EPS) & (t < b.t) & (__builtin_fabsf(xl) < 1.0f) & (__builtin_fabsf(yl) < 1.0f);
+    b.t = ok ? t : b.t;
+    b.id = ok ? id : b.id;
 }
 
-// Quadratic a t^2 + 2 h t + c = 0 (h = half the linear coefficient): picks the
-// root Shape::getIntersections + getNearestIntersection would keep.
-PTD void take_quadratic(float a, float h, float c, int k, Best& b) {
-    const float disc = __builtin_fmaf(h, h, -a * c);
-    const float s = fsqrt(disc);
-    const float ia = rcp(a);
+// Plane with explicit bounds (record: rows z, x, y | xMin, yMin, xMax, yMax).
+PTD void test_plane_gen(const float* R, V3 o, V3 d, int id, Best& b) {
+    const float oz = row_point(R, o);
+    const float dz = row_vec(R, d);
+    const float t = -oz * rcp(dz);
+    const V3 p = madd(d, t, o);
+    const float xl = row_point(R + 4, p), yl = row_point(R + 8, p);
+    const bool ok = (t > EPS) & (t < b.t) & (xl > R[12]) & (yl > R[13]) & (xl < R[14]) & (yl < R[15]);
+    b.t = ok ? t : b.t;
+    b.id = ok ? id : b.id;
+}
+
+// Quadratic a t^2 + 2 h t + c = 0 with ia = 1/a: the root Shape::getIntersections
+// + getNearestIntersection keep is the smaller one if it is beyond EPS, else the
+// larger.  A negative discriminant makes s NaN and every compare false.
+PTD void take_quadratic(float a, float ia, float h, float c, int id, Best& b) {
+    const float s = fsqrt(__builtin_fmaf(h, h, -a * c));
     const float t1 = (-h - s) * ia, t2 = (s - h) * ia;
     const float t = t1 > EPS ? t1 : t2;
-    const bool ok = (disc >= 0.0f) & (t > EPS) & (t < b.t);
-    if (ok) { b.t = t; b.prim = k; b.code = 0; }
+    const bool ok = (t > EPS) & (t < b.t);
+    b.t = ok ? t : b.t;
+    b.id = ok ? id : b.id;
 }
 
-PTD void test_sphere_ws(const float* R, V3 o, V3 d, float dd, int k, Best& b) {
+PTD void test_sphere_ws(const float* R, V3 o, V3 d, float dd, float idd, int id, Best& b) {
     const V3 oc = o - v3(R[0], R[1], R[2]);
-    take_quadratic(dd, dot(oc, d), dot(oc, oc) - R[3], k, b);
+    take_quadratic(dd, idd, dot(oc, d), dot(oc, oc) - R[3], id, b);
 }
 
-PTD void test_sphere(const float* R, V3 o, V3 d, int k, Best& b) {
+PTD void test_sphere(const float* R, V3 o, V3 d, int id, Best& b) {
     const V3 ol = v3(row_point(R, o), row_point(R + 4, o), row_point(R + 8, o));
     const V3 dl = v3(row_vec(R, d), row_vec(R + 4, d), row_vec(R + 8, d));
-    take_quadratic(dot(dl, dl), dot(dl, ol), dot(ol, ol) - 0.25f, k, b);
+    const float a = dot(dl, dl);
+    take_quadratic(a, rcp(a), dot(dl, ol), dot(ol, ol) - 0.25f, id, b);
 }
 
-PTD void test_cube(const float* R, V3 o, V3 d, int k, Best& b) {
+PTD void test_cube(const float* R, V3 o, V3 d, int id, Best& b) {
     const V3 ol = v3(row_point(R, o), row_point(R + 4, o), row_point(R + 8, o));
     const V3 dl = v3(row_vec(R, d), row_vec(R + 4, d), row_vec(R + 8, d));
     const float ix = rcp(dl.x), iy = rcp(dl.y), iz = rcp(dl.z);
     const float hx = 0.5f * __builtin_fabsf(ix), hy = 0.5f * __builtin_fabsf(iy), hz = 0.5f * __builtin_fabsf(iz);
-    const float cx = -ol.x * ix, cy = -ol.y * iy, cz = -ol.z * iz;
-    const float nx = cx - hx, ny = cy - hy, nz = cz - hz;   // entry distance per slab
-    const float fx = cx + hx, fy = cy + hy, fz = cz + hz;   // exit distance per slab
+    // entry / exit distance per slab
+    const float nx = __builtin_fmaf(-ol.x, ix, -hx), ny = __builtin_fmaf(-ol.y, iy, -hy), nz = __builtin_fmaf(-ol.z, iz, -hz);
+    const float fx = __builtin_fmaf(-ol.x, ix, hx), fy = __builtin_fmaf(-ol.y, iy, hy), fz = __builtin_fmaf(-ol.z, iz, hz);
     const float tmin = max3(nx, ny, nz), tmax = min3(fx, fy, fz);
     const bool use_exit = !(tmin > EPS);
     const float t = use_exit ? tmax : tmin;
-    const bool ok = (tmax >= 0.0f) & (tmin <= tmax) & (t > EPS) & (t < b.t);
+    // tmax >= 0 (shapes.h:191) is implied by t > EPS and tmin <= tmax.
+    const bool ok = (tmin <= tmax) & (t > EPS) & (t < b.t);
     if (ok) {
         const float ax = use_exit ? fx : nx, ay = use_exit ? fy : ny;
         const int axis = (ax == t) ? 0 : ((ay == t) ? 1 : 2);
-        b.t = t; b.prim = k; b.code = axis | (use_exit ? 4 : 0);
+        b.t = t;
+        b.id = id | axis | (use_exit ? 4 : 0);
     }
 }
 
 // Cylinder: the case analysis of shapes.h:231-318 in local space.
-PTD void test_cylinder(const float* R, V3 o, V3 d, int k, Best& b) {
+PTD void test_cylinder(const float* R, V3 o, V3 d, int id, Best& b) {
     const V3 ol = v3(row_point(R, o), row_point(R + 4, o), row_point(R + 8, o));
     const V3 dl = v3(row_vec(R, d), row_vec(R + 4, d), row_vec(R + 8, d));
     const float a = __builtin_fmaf(dl.x, dl.x, dl.y * dl.y);
@@ -153,22 +173,39 @@ PTD void test_cylinder(const float* R, V3 o, V3 d, int k, Best& b) {
         else if (e1) { valid = h2; t = t2; s = s2; }
         else if (e2) { valid = h1; t = t1; s = s1; }
         else { const bool sec = t2 < t1; valid = sec ? h2 : h1; t = sec ? t2 : t1; s = sec ? s2 : s1; }
-        if (valid && t < b.t) { b.t = t; b.prim = k; b.code = s; }
+        if (valid && t < b.t) { b.t = t; b.id = id | s; }
     }
 }
 
-// getNearestIntersection (shapes.h:79-100) over the whole table.
-PTD Best nearest(V3 o, V3 d, const FPrim* __restrict__ recs, const int32_t* __restrict__ tags, int n) {
-    Best b; b.t = __builtin_inff(); b.prim = -1; b.code = 0;
+// getNearestIntersection (shapes.h:79-100): runs of same-kind primitives in scene
+// order; every index below is wave-uniform, so records arrive by scalar loads.
+PTD Best nearest(V3 o, V3 d, const float* __restrict__ fdata, const FRun* __restrict__ runs, int n_runs) {
+    Best b; b.t = __builtin_inff(); b.id = -8;
     const float dd = dot(d, d);
-    for (int k = 0; k < n; k++) {
-        const float* R = recs[k].r;
-        switch (tags[k]) {
-            case FP_PLANE: test_plane(R, o, d, k, b); break;
-            case FP_SPHERE_WS: test_sphere_ws(R, o, d, dd, k, b); break;
-            case FP_CUBE: test_cube(R, o, d, k, b); break;
-            case FP_SPHERE: test_sphere(R, o, d, k, b); break;
-            default: test_cylinder(R, o, d, k, b); break;
+    const float idd = rcp(dd);
+    for (int r = 0; r < n_runs; r++) {
+        const FRun run = runs[r];
+        const float* R = fdata + run.offset;
+        int id = run.first << 3;
+        switch (run.type) {
+            case FP_PLANE:
+                for (int i = 0; i < run.count; i++, R += 12, id += 8) test_plane(R, o, d, id, b);
+                break;
+            case FP_SPHERE_WS:
+                for (int i = 0; i < run.count; i++, R += 4, id += 8) test_sphere_ws(R, o, d, dd, idd, id, b);
+                break;
+            case FP_CUBE:
+                for (int i = 0; i < run.count; i++, R += 12, id += 8) test_cube(R, o, d, id, b);
+                break;
+            case FP_SPHERE:
+                for (int i = 0; i < run.count; i++, R += 12, id += 8) test_sphere(R, o, d, id, b);
+                break;
+            case FP_PLANE_GEN:
+                for (int i = 0; i < run.count; i++, R += 16, id += 8) test_plane_gen(R, o, d, id, b);
+                break;
+            default:
+                for (int i = 0; i < run.count; i++, R += 12, id += 8) test_cylinder(R, o, d, id, b);
+                break;
         }
     }
     return b;
@@ -184,26 +221,27 @@ struct Surf {
 // shapes.h:93-97, from the per-primitive shading record.
 PTD Surf surface(const Best& b, V3 o, V3 d, const FShade* shade) {
     Surf s;
-    const FShade& S = shade[b.prim];
+    const FShade& S = shade[b.id >> 3];
+    const int code = b.id & 7;
     s.material = S.material;
     s.pos = madd(d, b.t, o);
     const int type = S.type;
     V3 n;
     bool inside_known = false, inside = false;
     if (type == PT_CYLINDER) {
-        if (b.code == 0) {
+        if (code == 0) {
             const float x = row_point(S.a + 9, s.pos), y = row_point(S.a + 13, s.pos);
             n = unit_or_zero(v3(__builtin_fmaf(S.a[0], x, S.a[3] * y), __builtin_fmaf(S.a[1], x, S.a[4] * y), __builtin_fmaf(S.a[2], x, S.a[5] * y)));
         } else {
-            const float sg = b.code == 1 ? 1.0f : -1.0f;
+            const float sg = code == 1 ? 1.0f : -1.0f;
             n = v3(S.a[6] * sg, S.a[7] * sg, S.a[8] * sg);
         }
     } else {
-        const int off = type == PT_CUBE ? (b.code & 3) * 3 : 0;
+        const int off = type == PT_CUBE ? (code & 3) * 3 : 0;
         n = v3(S.a[off], S.a[off + 1], S.a[off + 2]);
         if (type == PT_SPHERE) n = unit_or_zero(s.pos - n);
         if (type == PT_PLANE) { inside_known = true; inside = false; }
-        if (type == PT_CUBE) { inside_known = true; inside = (b.code & 4) != 0; }
+        if (type == PT_CUBE) { inside_known = true; inside = (code & 4) != 0; }
     }
     const bool along = dot(n, d) > 0.0f;
     s.inside = inside_known ? inside : along;
@@ -240,10 +278,10 @@ struct Path {
 };
 
 // One iteration of the tracePath loop (bsdf.h:78-166); true = continue.
-PTD bool path_step(Path& p, const FPrim* __restrict__ recs, const int32_t* __restrict__ tags, int n_prims,
+PTD bool path_step(Path& p, const float* __restrict__ fdata, const FRun* __restrict__ runs, int n_runs,
                    const FShade* shade, const DMat* mats, int n_bounces) {
-    const Best b = nearest(p.o, p.d, recs, tags, n_prims);
-    if (b.prim < 0) return false;
+    const Best b = nearest(p.o, p.d, fdata, runs, n_runs);
+    if (b.id < 0) return false;
     const Surf s = surface(b, p.o, p.d, shade);
     const DMat& M = mats[s.material];
     const V3 em = v3(M.emissive[0], M.emissive[1], M.emissive[2]);
@@ -355,7 +393,7 @@ struct FastTracer {
         p.seg = 0;
     }
     static PTD bool step(Path& p, const RenderArgs& a, FastCtx& c) {
-        return path_step(p, a.fprims, a.ftype, a.n_prims, c.shade, c.mats, a.n_bounces);
+        return path_step(p, a.fdata, a.runs, a.n_runs, c.shade, c.mats, a.n_bounces);
     }
     static PTD void radiance(const Path& p, float rgb[3]) { rgb[0] = p.contrib.x; rgb[1] = p.contrib.y; rgb[2] = p.contrib.z; }
 };
@@ -387,7 +425,7 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, u
     ptw::render_tile<FastTracer>(a, tile, acc[wave], ctx);
 }
 
-__global__ __launch_bounds__(256) void trace_fast_kernel(const FPrim* __restrict__ recs, const int32_t* __restrict__ tags, int n_prims,
+__global__ __launch_bounds__(256) void trace_fast_kernel(const float* __restrict__ fdata, const FRun* __restrict__ runs, int n_runs,
                                                          const FShade* __restrict__ shade, const DMat* __restrict__ mats,
                                                          const float* __restrict__ o, const float* __restrict__ d,
                                                          const uint32_t* __restrict__ pixel, const uint32_t* __restrict__ sample,
@@ -399,7 +437,7 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(const FPrim* __restrict
     p.o = v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
     p.d = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     p.coef = v3(1.0f, 1.0f, 1.0f); p.contrib = v3(0.0f, 0.0f, 0.0f); p.seg = 0;
-    while (path_step(p, recs, tags, n_prims, shade, mats, n_bounces)) {}
+    while (path_step(p, fdata, runs, n_runs, shade, mats, n_bounces)) {}
     rgb[3 * i] = p.contrib.x; rgb[3 * i + 1] = p.contrib.y; rgb[3 * i + 2] = p.contrib.z;
 }
 
@@ -421,7 +459,7 @@ int ptk_render_fast(const RenderArgs& a, hipStream_t s) {
 int ptk_trace_paths_fast(const pt_scene* sc, const float* o, const float* d, const uint32_t* pixel,
                          const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, float* rgb, hipStream_t s) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(trace_fast_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sc->d_fprims, sc->d_ftype, sc->n_prims,
+    hipLaunchKernelGGL(trace_fast_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sc->d_fdata, sc->d_runs, sc->n_runs,
                        sc->d_fshade, sc->d_mats, o, d, pixel, sample, n, seed_hash, n_bounces, rgb);
     PT_CHECK(hipGetLastError());
     return 0;

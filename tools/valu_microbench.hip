@@ -12,7 +12,7 @@
 #define REP8(x) x x x x x x x x
 #define REP64(x) REP8(REP8(x))
 
-constexpr int ITERS = 1000;         // 1000 * 64 = 64000 instructions per wave
+constexpr int ITERS = 10000;        // 10000 * 64 = 640000 instructions per wave (milliseconds per launch: clocks settle)
 
 #define KERNEL(name, body, pre)                                                                   \
     __global__ __launch_bounds__(256) void k_##name(unsigned long long* out, float seed) {        \
@@ -21,13 +21,16 @@ constexpr int ITERS = 1000;         // 1000 * 64 = 64000 instructions per wave
         float b = seed * 0.5f + 1.0f, c = seed + 0.25f;                                           \
         unsigned long long m = 0; (void)m;                                                        \
         pre;                                                                                      \
+        unsigned long long r0 = __builtin_amdgcn_s_memrealtime();                                 \
         unsigned long long t0 = __builtin_amdgcn_s_memtime();                                     \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
         for (int it = 0; it < ITERS; it++) {                                                      \
             REP8(body)                                                                            \
         }                                                                                         \
         unsigned long long t1 = __builtin_amdgcn_s_memtime();                                     \
+        unsigned long long r1 = __builtin_amdgcn_s_memrealtime();                                 \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+        if (blockIdx.x == 0 && threadIdx.x == 0) out[1 + 8 * 256 * 4] = r1 - r0;                  \
         float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                                          \
         if (s == 12345.678f) out[0] = 1;                                                          \
         if ((threadIdx.x & 63) == 0) out[1 + blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;      \
@@ -144,11 +147,14 @@ __global__ __launch_bounds__(256) void k_pk_fma(unsigned long long* out, float s
     float a0 = seed + threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
     float b = seed * 0.5f + 1.0f, c = seed + 0.25f;
     PKPRE
+    unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     for (int it = 0; it < ITERS; it++) { REP8(OPPK("v_pk_fma_f32")) }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[1 + 8 * 256 * 4] = r1 - r0;
     float s = p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
     if (s == 12345.678f) out[0] = 1;
     if ((threadIdx.x & 63) == 0) out[1 + blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
@@ -160,25 +166,27 @@ struct Entry { const char* name; kern_t k; };
 int main() {
     std::vector<Entry> ks = {
 #define E(n) {#n, k_##n}
-        E(fma), E(mul), E(add), E(max), E(max3), E(med3), E(cmp_vcc), E(cmp_sgpr), E(cndmask), E(mul_lo_u32), E(mul_hi_u32),
-        E(mad_u32_u24), E(mul_u32_u24), E(xor), E(lshrrev), E(add_u32), E(xad_u32), E(lshl_add_u32), E(alignbit),
-        E(rcp), E(rsq), E(sqrt), E(sin), E(exp), E(cvt_f32_u32), E(pk_fma), E(fma_sgpr), E(mul_sgpr), E(fmac), E(min), E(sub), E(mov), E(and), E(bfe_u32), E(cndmask_sgpr), E(cndmask_2src), E(cmp_sel_mix), E(salu), E(mix_fma_salu)};
+        E(fma), E(mul), E(add), E(sub), E(fmac), E(mov), E(xor), E(and), E(lshrrev), E(add_u32), E(fma_sgpr), E(mul_sgpr),
+        E(max), E(min), E(max3), E(med3), E(cmp_vcc), E(cmp_sgpr), E(cndmask_sgpr), E(cndmask), E(cndmask_2src), E(cmp_sel_mix),
+        E(mul_lo_u32), E(mul_hi_u32), E(mad_u32_u24), E(mul_u32_u24), E(xad_u32), E(lshl_add_u32), E(alignbit), E(bfe_u32),
+        E(cvt_f32_u32), E(pk_fma), E(rcp), E(rsq), E(sqrt), E(sin), E(exp), E(salu), E(mix_fma_salu)};
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
-    printf("device %s, %d CUs\n", prop.name, cus);
+    printf("device %s, %d CUs; %d instructions per wave per launch\n", prop.gcnArchName, cus, ITERS * 64);
     unsigned long long* d;
     const int max_blocks = cus * 8;
-    hipMalloc(&d, sizeof(unsigned long long) * (1 + max_blocks * 4));
-    std::vector<unsigned long long> h(1 + max_blocks * 4);
-    printf("%-16s %10s %10s %10s %10s   (shader cycles per wave-instruction per SIMD; 256-thread blocks, W blocks per CU)\n", "instruction", "W=1", "W=2", "W=4", "W=8");
+    hipMalloc(&d, sizeof(unsigned long long) * (2 + max_blocks * 4));
+    std::vector<unsigned long long> h(2 + max_blocks * 4);
+    printf("%-14s | wave-instructions per ns per SIMD from wall time (W x 256-thread blocks per CU = W waves per SIMD) | one wave alone: shader cycles per instruction\n", "instruction");
+    printf("%-14s %8s %8s %8s %8s | %8s\n", "", "W=1", "W=2", "W=4", "W=8", "cycles");
     const double n_instr = (double)ITERS * 64.0;
     for (auto& e : ks) {
-        printf("%-16s", e.name);
-        float wall8 = 0;
+        printf("%-14s", e.name);
+        double cyc1 = 0;
         for (int w : {1, 2, 4, 8}) {
             const int blocks = cus * w;
-            hipMemset(d, 0, sizeof(unsigned long long) * (1 + max_blocks * 4));
+            hipMemset(d, 0, sizeof(unsigned long long) * (2 + max_blocks * 4));
             hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, d, 1.0f);   // warm-up
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             hipEventRecord(e0, 0);
@@ -186,16 +194,16 @@ int main() {
             hipEventRecord(e1, 0);
             hipDeviceSynchronize();
             float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-            if (w == 8) wall8 = ms;
-            hipMemcpy(h.data(), d, sizeof(unsigned long long) * (1 + blocks * 4), hipMemcpyDeviceToHost);
-            std::vector<unsigned long long> v(h.begin() + 1, h.begin() + 1 + blocks * 4);
-            std::sort(v.begin(), v.end());
-            const double med = (double)v[v.size() / 2];
-            // a wave's stream took `med` cycles while W waves shared its SIMD
-            printf(" %10.2f", med / n_instr / w);
+            hipEventDestroy(e0); hipEventDestroy(e1);
+            if (w == 1) {
+                hipMemcpy(h.data(), d, sizeof(unsigned long long) * (2 + max_blocks * 4), hipMemcpyDeviceToHost);
+                std::vector<unsigned long long> v(h.begin() + 1, h.begin() + 1 + blocks * 4);
+                std::sort(v.begin(), v.end());
+                cyc1 = (double)v[v.size() / 2] / n_instr;
+            }
+            printf(" %8.3f", n_instr * w / (ms * 1e6));
         }
-        // wall-clock cross-check at W=8: wave-instructions per ns per SIMD
-        printf("   | W=8 wall %.1f us -> %.3f wave-instr/ns/SIMD\n", wall8 * 1e3, n_instr * 8.0 / (wall8 * 1e6));
+        printf(" | %8.2f\n", cyc1);
     }
     hipFree(d);
     return 0;
