@@ -1,0 +1,223 @@
+// pathtracer — the reference's host flow (main.cu:200-257) on MI355X: build the
+// scene with the Shape constructors, render through the C ABI, print the image as
+// ASCII PPM (P3) on stdout with scanline progress on stderr.  Every literal of
+// the reference's main() is a flag here whose default is that literal:
+//   --width 800 --height 800 --spp 2000 --depth 5 --seed 0 --math fast
+//   --scene default|glass[N]|synthetic  --gpus 1  --stats
+// Usage, as in the reference's readme:  pathtracer > out.ppm
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/pt/api.h"
+
+// constructScene (main.cu:71-198) as a host function: same transforms, same
+// materials, same eleven `new` expressions.
+static int constructScene(Shape** scene) {
+    Affine3f floor = IDENTITY;
+    floor.linear() = AngleAxisf(PI / 2, vec3(1, 0, 0)).toRotationMatrix();
+    floor.translation() = Translation3f(0.0, -1.0, 0.0).translation();
+    Affine3f back = IDENTITY;
+    back.translation() = Translation3f(0.0, 0, -5.0).translation();
+    Affine3f left = IDENTITY;
+    left.linear() = AngleAxisf(PI / 2, vec3(0, 1, 0)).toRotationMatrix();
+    left.translation() = Translation3f(-1.0, 0.0, -5.0).translation();
+    Affine3f right = IDENTITY;
+    right.linear() = AngleAxisf(-PI / 2, vec3(0, 1, 0)).toRotationMatrix();
+    right.translation() = Translation3f(1.0, 0.0, -5.0).translation();
+    Affine3f ceiling = IDENTITY;
+    ceiling.linear() = AngleAxisf(-PI / 2, vec3(1, 0, 0)).toRotationMatrix();
+    ceiling.translation() = Translation3f(0.0, 1.0, 0.0).translation();
+    Affine3f light = IDENTITY;
+    light.linear() = AngleAxisf(-PI / 2, vec3(1, 0, 0)).toRotationMatrix();
+    light.translation() = Translation3f(0.0, 0.97, -3.25).translation();
+    Affine3f tplane6 = IDENTITY;
+    tplane6.linear() = AngleAxisf(PI, vec3(0, 1, 0)).toRotationMatrix();
+    tplane6.translation() = Translation3f(0.0, 0.0, 7.0).translation();
+    Affine3f t5 = IDENTITY;
+    t5.translation() = Translation3f(0.0, -0.5, -3.0).translation();
+    t5.scale(0.4f);
+    Affine3f t6 = IDENTITY;
+    t6.translation() = Translation3f(0.6, -0.5, -3.0).translation();
+    t6.scale(0.4f);
+    Affine3f t7 = IDENTITY;
+    t7.translation() = Translation3f(-0.6, -0.5, -3.0).translation();
+    t7.scale(0.4f);
+    Affine3f t8 = IDENTITY;
+    t8.translation() = Translation3f(0.0f, -0.5f, -4.2f).translation();
+    t8.scale(vec3(2.5f, 0.3f, 0.5f));
+
+    Material light_material;
+    light_material.emissive = vec3(1.0f, 0.9f, 0.7f) * 20.0f;
+    Material base;
+    base.albedo = vec3(0.4f, 0.4f, 0.4f);
+    Material green;
+    green.albedo = vec3(0.0f, 1.0f, 0.0f);
+    Material red;
+    red.albedo = vec3(1.0f, 0.0f, 0.0f);
+    Material glass;
+    glass.f0 = 0.02f;
+    glass.specularRoughness = 0;
+    glass.specularColor = vec3(1.0f, 1.0f, 1.0f) * 0.8f;
+    glass.IOR = 1.5f;
+    glass.transparency = 1.0f;
+    glass.refractionRoughness = 0.0f;
+    glass.bsdfType = 1;
+    Material diffuse_pure;
+    diffuse_pure.albedo = vec3(0.6f, 0.6f, 0.6f);
+    Material glass1 = glass, glass2 = glass, glass3 = glass;
+    glass2.refractionColor = vec3(0.9f, 0.0f, 0.0f);
+    glass3.refractionColor = vec3(2.0f, 0.0f, 0.0f);
+
+    scene[0] = new Plane(base, floor, -15.0f, -15.0f, 15.0f, 15.0f);
+    scene[1] = new Plane(red, left, -15.0f, -15.0f, 15.0f, 15.0f);
+    scene[2] = new Plane(green, right, -15.0f, -15.0f, 15.0f, 15.0f);
+    scene[3] = new Plane(base, back, -15.0f, -15.0f, 15.0f, 15.0f);
+    scene[4] = new Plane(base, ceiling, -15.0f, -15.0f, 15.0f, 15.0f);
+    scene[5] = new Plane(light_material, light, -0.5f, -0.5f, 0.5f, 0.5f);
+    scene[6] = new Plane(base, tplane6, -15.0f, -15.0f, 15.0f, 15.0f);
+    scene[7] = new Sphere(glass1, t7);
+    scene[8] = new Sphere(glass2, t5);
+    scene[9] = new Sphere(glass3, t6);
+    scene[10] = new Cube(diffuse_pure, t8);
+    return 11;
+}
+
+// Shapes from a flat description (the library's glass-grid and synthetic builders).
+static int shapesFromTable(const std::vector<pt_prim>& prims, const std::vector<pt_material>& mats, std::vector<Shape*>& scene) {
+    for (const pt_prim& p : prims) {
+        Material m;
+        const pt_material& a = mats[p.material];
+        m.albedo = vec3(a.albedo[0], a.albedo[1], a.albedo[2]); m.emissive = vec3(a.emissive[0], a.emissive[1], a.emissive[2]);
+        m.f0 = a.f0; m.specularRoughness = a.specularRoughness; m.specularColor = vec3(a.specularColor[0], a.specularColor[1], a.specularColor[2]);
+        m.IOR = a.IOR; m.transparency = a.transparency; m.refractionRoughness = a.refractionRoughness;
+        m.refractionColor = vec3(a.refractionColor[0], a.refractionColor[1], a.refractionColor[2]); m.bsdfType = a.bsdfType;
+        Affine3f t;
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) t.m[i][j] = p.transform[i * 4 + j];
+        switch (p.type) {
+            case PT_PLANE: scene.push_back(new Plane(m, t, p.bounds[0], p.bounds[1], p.bounds[2], p.bounds[3])); break;
+            case PT_CUBE: scene.push_back(new Cube(m, t)); break;
+            case PT_CYLINDER: scene.push_back(new Cylinder(m, t)); break;
+            default: scene.push_back(new Sphere(m, t)); break;
+        }
+    }
+    return (int)scene.size();
+}
+
+int main(int argc, char** argv) {
+    int nx = 800, ny = 800, n_gpus = 1;
+    render_options opt;                 // n_samples 2000, n_bounces 5 as in the reference
+    std::string scene_name = "default";
+    bool stats = false;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto next = [&]() -> const char* { if (i + 1 >= argc) { std::cerr << "missing value for " << a << "\n"; std::exit(2); } return argv[++i]; };
+        if (a == "--width") nx = std::atoi(next());
+        else if (a == "--height") ny = std::atoi(next());
+        else if (a == "--spp") opt.n_samples = std::atoi(next());
+        else if (a == "--depth") opt.n_bounces = std::atoi(next());
+        else if (a == "--seed") opt.seed = (unsigned)std::strtoul(next(), nullptr, 10);
+        else if (a == "--math") opt.math_mode = std::string(next()) == "parity" ? PT_MATH_PARITY : PT_MATH_FAST;
+        else if (a == "--scene") scene_name = next();
+        else if (a == "--gpus") n_gpus = std::atoi(next());
+        else if (a == "--stats") stats = true;
+        else { std::cerr << "unknown flag " << a << "\n"; return 2; }
+    }
+    if (nx <= 0 || ny <= 0 || n_gpus < 1) { std::cerr << "bad size or gpu count\n"; return 2; }
+    int n_dev = 0;
+    checkHipErrors(hipGetDeviceCount(&n_dev));
+    if (n_gpus > n_dev) { std::cerr << "asked for " << n_gpus << " GPUs, " << n_dev << " visible\n"; return 2; }
+
+    /* Scene */
+    std::vector<Shape*> scene;
+    if (scene_name == "default") {
+        scene.resize(11);
+        constructScene(scene.data());
+    } else {
+        std::vector<pt_prim> prims;
+        std::vector<pt_material> mats(8);
+        int nm = 0, n = 0;
+        if (scene_name.rfind("glass", 0) == 0) {
+            const int g = scene_name.size() > 5 ? std::atoi(scene_name.c_str() + 5) : 5;
+            prims.resize(8 + (size_t)g * g);
+            n = pt_glass_grid_scene(g, prims.data(), mats.data(), &nm);
+        } else if (scene_name == "synthetic") {
+            prims.resize(10000);
+            n = pt_synthetic_scene(5000, 4989, 12345u, prims.data(), mats.data(), &nm);
+        } else { std::cerr << "unknown scene " << scene_name << "\n"; return 2; }
+        prims.resize((size_t)n);
+        shapesFromTable(prims, mats, scene);
+    }
+    const int n_objs = (int)scene.size();
+
+    /* Camera (main.cu:229-234; nx/ny is an integer division there) */
+    float v_height = 5.0;
+    float v_width = nx / ny * v_height;
+    float fov = 45;
+    float focal_length = (v_width / 2) / tan(DEG_TO_RAD(fov / 2));
+    config_t config = {vec3(0, 0, 0), nx, ny, focal_length, v_height};
+
+    /* Render: GPU g owns rows [g*rows, (g+1)*rows); every tile lands in the host image */
+    const size_t num_pixels = (size_t)nx * ny;
+    std::vector<vec3> fb(num_pixels);
+    const int rows = (ny + n_gpus - 1) / n_gpus;
+    std::vector<double> ms(n_gpus, 0.0);
+    auto worker = [&](int g) {
+        checkHipErrors(hipSetDevice(g));
+        render_options o = opt;
+        o.device = g;
+        o.row_begin = std::min(ny, g * rows);
+        o.row_end = std::min(ny, o.row_begin + rows);
+        if (o.row_end <= o.row_begin) return;
+        pt::DeviceScene dscene(scene.data(), n_objs, g);
+        vec3* d_fb = nullptr;
+        checkHipErrors(hipMalloc((void**)&d_fb, num_pixels * sizeof(vec3)));
+        hipEvent_t e0, e1;
+        checkHipErrors(hipEventCreate(&e0)); checkHipErrors(hipEventCreate(&e1));
+        checkHipErrors(hipEventRecord(e0, nullptr));
+        render(d_fb, config, dscene, o);
+        checkHipErrors(hipEventRecord(e1, nullptr));
+        checkHipErrors(hipGetLastError());
+        checkHipErrors(hipDeviceSynchronize());
+        float t = 0.0f;
+        checkHipErrors(hipEventElapsedTime(&t, e0, e1));
+        ms[g] = t;
+        const size_t off = (size_t)o.row_begin * nx, cnt = (size_t)(o.row_end - o.row_begin) * nx;
+        checkHipErrors(hipMemcpy(fb.data() + off, d_fb + off, cnt * sizeof(vec3), hipMemcpyDeviceToHost));
+        checkHipErrors(hipFree(d_fb));
+    };
+    std::vector<std::thread> threads;
+    for (int g = 1; g < n_gpus; g++) threads.emplace_back(worker, g);
+    worker(0);
+    for (auto& t : threads) t.join();
+
+    if (stats) {
+        double worst = 0.0;
+        for (double t : ms) worst = std::max(worst, t);
+        const double samples = (double)num_pixels * opt.n_samples;
+        std::clog << "{\"width\": " << nx << ", \"height\": " << ny << ", \"spp\": " << opt.n_samples << ", \"depth\": " << opt.n_bounces
+                  << ", \"gpus\": " << n_gpus << ", \"kernel_ms\": " << worst << ", \"msamples_per_s\": " << samples / worst / 1e3 << "}\n";
+    }
+
+    /* Output as PPM Image (main.cu:239-253) */
+    std::cout << "P3\n" << nx << " " << ny << "\n255\n";
+    for (int j = ny - 1; j >= 0; j--) {
+        std::clog << "\rScanlines remaining: " << (ny - j) << ' ' << std::flush;
+        for (int i = 0; i < nx; i++) {
+            size_t pixel_index = (size_t)j * nx + i;
+            float r = fb[pixel_index].x();
+            float g = fb[pixel_index].y();
+            float b = fb[pixel_index].z();
+            int ir = int(255.99 * r);
+            int ig = int(255.99 * g);
+            int ib = int(255.99 * b);
+            std::cout << ir << " " << ig << " " << ib << "\n";
+        }
+    }
+    for (Shape* s : scene) delete s;
+    return 0;
+}
