@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 FP32_VALU_PEAK_TFLOPS = 157.3      # 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz
 WIDTH, HEIGHT, SPP, DEPTH, SEED = 1920, 1080, 64, 5, 0
 FLOPS_KEY = "default_1920x1080_64spp_depth5_seed0"
-CPU_ROW_STEP = 4                   # cpu_baseline sample: every 4th row of the frame
+CPU_ROW_STEP = 1                   # cpu_baseline sample: every CPU_ROW_STEP-th row of the frame (1 = the whole frame)
 
 
 def flops_per_sample():
@@ -53,8 +53,8 @@ def cpu_baseline(gpu_image):
     dt = time.perf_counter() - t0
     samples = len(rows) * WIDTH * SPP
     base = {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": "rows j %% %d == 0 of the same 1920x1080 64-spp frame (%d rows, %.1f Msamples, %.1f s)"
-                      % (CPU_ROW_STEP, len(rows), samples / 1e6, dt)}
+            "sample": "%s of the same 1920x1080 64-spp frame (%d rows, %.1f Msamples, %.1f s)"
+                      % ("every row" if CPU_ROW_STEP == 1 else "rows j %% %d == 0" % CPU_ROW_STEP, len(rows), samples / 1e6, dt)}
     img = gpu_image.cpu().numpy()[rows].astype(np.float64)
     ref = ref[rows].astype(np.float64)
     parity = {"rows": int(len(rows)),
