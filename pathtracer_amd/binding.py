@@ -9,6 +9,7 @@ import ctypes as C
 import os
 
 import numpy as np
+import torch  # noqa: F401  (first: torch must bring up ITS HIP runtime before libpt_hip.so loads one)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpt_hip.so")
@@ -143,7 +144,6 @@ def ppm_p3(fb):
 
 
 def _torch():
-    import torch
     return torch
 
 
