@@ -19,6 +19,23 @@
 
 #define PTD __device__ __forceinline__
 
+// Development aid (make prof): per-phase shader-cycle shares of the render loop, stamped with s_memtime.
+// Phases: 0 refill, 1 nearest, 2 surface + material fetch, 3 emissive/Beer/Fresnel/mode, 4 direction, 5 throughput +
+// roulette, 6 accumulate.  Not compiled into libpt_hip.so.
+#ifdef PT_PHASE_PROF
+__device__ unsigned long long g_phase_cycles[8];
+struct PhaseClock {
+    unsigned long long last, acc[8];
+    __device__ void start() { for (int i = 0; i < 8; i++) acc[i] = 0; last = __builtin_amdgcn_s_memtime(); }
+    __device__ void mark(int i) { const unsigned long long now = __builtin_amdgcn_s_memtime(); acc[i] += now - last; last = now; }
+    __device__ void flush(unsigned lane) { if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_phase_cycles[i], acc[i]); }
+};
+#define PHASE(clk, i) (clk).mark(i)
+#else
+struct PhaseClock { __device__ void start() {} __device__ void mark(int) {} __device__ void flush(unsigned) {} };
+#define PHASE(clk, i) do { } while (0)
+#endif
+
 namespace ptf {
 
 struct V3 { float x, y, z; };
@@ -36,7 +53,8 @@ PTD float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 PTD float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 PTD float max3(float a, float b, float c) { return __builtin_fmaxf(a, __builtin_fmaxf(b, c)); }
 PTD float min3(float a, float b, float c) { return __builtin_fminf(a, __builtin_fminf(b, c)); }
-// Unit vector; the caller guarantees a non-zero input.
+// Unit vector.  A zero input gives NaNs where Eigen's normalized() returns the zero vector; for a ray direction
+// both mean the same thing one segment later: no primitive test passes, the path ends as a miss.
 PTD V3 unit(V3 a) { return a * rsq(dot(a, a)); }
 // Unit vector that leaves the zero vector alone (Eigen's normalized()).
 PTD V3 unit_or_zero(V3 a) { float n = dot(a, a); return n > 0.0f ? a * rsq(n) : a; }
@@ -239,7 +257,7 @@ PTD Surf surface(const Best& b, V3 o, V3 d, const FShade* shade) {
     } else {
         const int off = type == PT_CUBE ? (code & 3) * 3 : 0;
         n = v3(S.a[off], S.a[off + 1], S.a[off + 2]);
-        if (type == PT_SPHERE) n = unit_or_zero(s.pos - n);
+        if (type == PT_SPHERE) n = unit(s.pos - n);
         if (type == PT_PLANE) { inside_known = true; inside = false; }
         if (type == PT_CUBE) { inside_known = true; inside = (code & 4) != 0; }
     }
@@ -279,12 +297,14 @@ struct Path {
 
 // One iteration of the tracePath loop (bsdf.h:78-166); true = continue.
 PTD bool path_step(Path& p, const float* __restrict__ fdata, const FRun* __restrict__ runs, int n_runs,
-                   const FShade* shade, const DMat* mats, int n_bounces) {
+                   const FShade* shade, const DMat* mats, int n_bounces, PhaseClock& clk) {
     const Best b = nearest(p.o, p.d, fdata, runs, n_runs);
+    PHASE(clk, 1);
     if (b.id < 0) return false;
     const Surf s = surface(b, p.o, p.d, shade);
     const DMat& M = mats[s.material];
     const V3 em = v3(M.emissive[0], M.emissive[1], M.emissive[2]);
+    PHASE(clk, 2);
     if ((max3(em.x, em.y, em.z) > 0.0f) || (min3(em.x, em.y, em.z) < 0.0f)) p.contrib = v3(__builtin_fmaf(em.x, p.coef.x, p.contrib.x), __builtin_fmaf(em.y, p.coef.y, p.contrib.y), __builtin_fmaf(em.z, p.coef.z, p.contrib.z));
     const float f0 = M.f0, transparency = M.transparency;
     float p_specular = f0, p_refract = transparency;
@@ -310,6 +330,7 @@ PTD bool path_step(Path& p, const float* __restrict__ fdata, const FRun* __restr
         else if (p_refract > 0.0f && u < p_specular + p_refract) { mode = 2; p_ray = p_refract; }
     }
     p_ray = __builtin_fmaxf(p_ray, 0.001f);
+    PHASE(clk, 3);
     V3 ndir;
     V3 tint;
     if (mode == 2) {
@@ -317,20 +338,20 @@ PTD bool path_step(Path& p, const float* __restrict__ fdata, const FRun* __restr
         const float ndi = dot(s.nrm, p.d);
         const float k = __builtin_fmaf(-eta * eta, __builtin_fmaf(-ndi, ndi, 1.0f), 1.0f);
         V3 rd = v3(0.0f, 0.0f, 0.0f);
-        if (!(k < 0.0f)) rd = unit_or_zero(madd(s.nrm, -__builtin_fmaf(eta, ndi, fsqrt(k)), p.d * eta));
+        if (!(k < 0.0f)) rd = unit(madd(s.nrm, -__builtin_fmaf(eta, ndi, fsqrt(k)), p.d * eta));
         const float rr = M.refractionRoughness * M.refractionRoughness;
         if (rr != 0.0f) {
-            const V3 hd = unit_or_zero(s.nrm + sphere_point(rng_u(p.key, slot + 3u), rng_u(p.key, slot + 4u)));
-            rd = unit_or_zero(madd(hd, rr, rd * (1.0f - rr)));
+            const V3 hd = unit(s.nrm + sphere_point(rng_u(p.key, slot + 3u), rng_u(p.key, slot + 4u)));
+            rd = unit(madd(hd, rr, rd * (1.0f - rr)));
         }
         ndir = rd;
         tint = v3(1.0f, 1.0f, 1.0f);
     } else {
-        const V3 dd = unit_or_zero(s.nrm + sphere_point(rng_u(p.key, slot + 1u), rng_u(p.key, slot + 2u)));
+        const V3 dd = unit(s.nrm + sphere_point(rng_u(p.key, slot + 1u), rng_u(p.key, slot + 2u)));
         if (mode == 1) {
-            V3 sd = unit_or_zero(madd(s.nrm, -2.0f * dot(p.d, s.nrm), p.d));
+            V3 sd = unit(madd(s.nrm, -2.0f * dot(p.d, s.nrm), p.d));
             const float sr = M.specularRoughness * M.specularRoughness;
-            if (sr != 0.0f) sd = unit_or_zero(madd(dd, sr, sd * (1.0f - sr)));
+            if (sr != 0.0f) sd = unit(madd(dd, sr, sd * (1.0f - sr)));
             ndir = sd;
             tint = v3(M.specularColor[0], M.specularColor[1], M.specularColor[2]);
         } else {
@@ -338,6 +359,7 @@ PTD bool path_step(Path& p, const float* __restrict__ fdata, const FRun* __restr
             tint = v3(M.albedo[0], M.albedo[1], M.albedo[2]);
         }
     }
+    PHASE(clk, 4);
     p.coef = p.coef * tint * rcp(p_ray);
     const float q = max3(p.coef.x, p.coef.y, p.coef.z);
     // Russian roulette (bsdf.h:160-164): u in (0,1], so q >= 1 always survives
@@ -366,6 +388,7 @@ struct FastCtx {
     const FShade* shade;   // LDS or global
     const DMat* mats;      // LDS or global
     float* pxt;            // LDS, this wave's [3][64]: i-0.5, H-j-0.5, K_px bits
+    PhaseClock clk;
 };
 
 struct FastTracer {
@@ -387,15 +410,16 @@ struct FastTracer {
         const V3 cam = v3(a.cam[0], a.cam[1], a.cam[2]);
         const V3 pc = v3(__builtin_fmaf(a.du, sx, a.p00[0]), __builtin_fmaf(a.dv, sy, a.p00[1]), a.p00[2]);
         p.o = cam;
-        p.d = unit_or_zero(pc - cam);
+        p.d = unit(pc - cam);
         p.coef = v3(1.0f, 1.0f, 1.0f);
         p.contrib = v3(0.0f, 0.0f, 0.0f);
         p.seg = 0;
     }
     static PTD bool step(Path& p, const RenderArgs& a, FastCtx& c) {
-        return path_step(p, a.fdata, a.runs, a.n_runs, c.shade, c.mats, a.n_bounces);
+        return path_step(p, a.fdata, a.runs, a.n_runs, c.shade, c.mats, a.n_bounces, c.clk);
     }
     static PTD void radiance(const Path& p, float rgb[3]) { rgb[0] = p.contrib.x; rgb[1] = p.contrib.y; rgb[2] = p.contrib.z; }
+    static PTD void phase(FastCtx& c, int i) { PHASE(c.clk, i); (void)c; (void)i; }
 };
 
 template <bool LDS_TABLES>
@@ -422,7 +446,9 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, u
     const uint32_t tile = blockIdx.x * ptw::WAVES_PER_BLOCK + wave;
     if (tile >= n_tiles) return;
     ctx.pxt = pxt[wave];
+    ctx.clk.start();
     ptw::render_tile<FastTracer>(a, tile, acc[wave], ctx);
+    ctx.clk.flush(threadIdx.x & 63);
 }
 
 __global__ __launch_bounds__(256) void trace_fast_kernel(const float* __restrict__ fdata, const FRun* __restrict__ runs, int n_runs,
@@ -437,11 +463,21 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(const float* __restrict
     p.o = v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
     p.d = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     p.coef = v3(1.0f, 1.0f, 1.0f); p.contrib = v3(0.0f, 0.0f, 0.0f); p.seg = 0;
-    while (path_step(p, fdata, runs, n_runs, shade, mats, n_bounces)) {}
+    PhaseClock clk;
+    while (path_step(p, fdata, runs, n_runs, shade, mats, n_bounces, clk)) {}
     rgb[3 * i] = p.contrib.x; rgb[3 * i + 1] = p.contrib.y; rgb[3 * i + 2] = p.contrib.z;
 }
 
 }  // namespace
+
+#ifdef PT_PHASE_PROF
+extern "C" int pt_dev_phase_cycles(unsigned long long* out, int reset) {
+    PT_CHECK(hipDeviceSynchronize());
+    PT_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 8 * sizeof(unsigned long long)));
+    if (reset) { unsigned long long z[8] = {0}; PT_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z))); }
+    return 0;
+}
+#endif
 
 int ptk_render_fast(const RenderArgs& a, hipStream_t s) {
     const uint32_t npix = a.pix_end - a.pix_begin;

@@ -27,6 +27,7 @@ struct ParityTracer {
     static __device__ __forceinline__ void radiance(const Path& p, float rgb[3]) {
         rgb[0] = p.contrib.x; rgb[1] = p.contrib.y; rgb[2] = p.contrib.z;
     }
+    static __device__ __forceinline__ void phase(ParityCtx&, int) {}
 };
 
 __global__ __launch_bounds__(ptw::BLOCK) void render_parity_kernel(RenderArgs a, uint32_t n_tiles) {

@@ -33,6 +33,7 @@ __device__ __forceinline__ unsigned prefix_count(unsigned long long mask) {
 //              static void start(Path&, const RenderArgs&, Ctx&, uint32_t px, uint32_t pixel_index, uint32_t sample);
 //              static bool step(Path&, const RenderArgs&, Ctx&);     // true = path continues
 //              static void radiance(const Path&, float rgb[3]);
+//              static void phase(Ctx&, int);                          // development profiling hook, normally empty
 template <class T, class Ctx>
 __device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, float* acc /* LDS, 192 floats of this wave */, Ctx& ctx) {
     const unsigned lane = lane_id();
@@ -62,12 +63,14 @@ __device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, 
                 }
             }
         }
+        T::phase(ctx, 0);
         if (__ballot(active) == 0ull) {
             if (next >= total) break;
             continue;
         }
         if (active) {
             const bool go_on = T::step(path, a, ctx);
+            T::phase(ctx, 5);
             if (!go_on) {
                 float rgb[3];
                 T::radiance(path, rgb);
@@ -77,6 +80,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, 
                 active = false;
             }
         }
+        T::phase(ctx, 6);
     }
 
     // p_color = totalLight / n_samples (main.cu:67), then the tile leaves as
