@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--math", choices=["fast", "parity"], default="fast")
+    ap.add_argument("--math", choices=["fast", "parity", "scalar", "lds"], default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -93,7 +93,7 @@ def main():
 
     prims, n, mats, nm = pt.default_scene()
     scene = pt.Scene(prims, n, mats, nm, device=local_rank)
-    math_mode = pt.PT_MATH_FAST if args.math == "fast" else pt.PT_MATH_PARITY
+    math_mode = {"fast": pt.PT_MATH_FAST, "parity": pt.PT_MATH_PARITY, "scalar": pt.PT_MATH_FAST_SCALAR, "lds": pt.PT_MATH_FAST_LDS}[args.math]
     begin, end = multigpu.row_tile(HEIGHT, rank, world)
     cfg = pt.make_config(WIDTH, HEIGHT, SPP, n_bounces=DEPTH, seed=SEED, row_begin=begin, row_end=end, math_mode=math_mode)
     fb = multigpu.alloc_framebuffer(HEIGHT, WIDTH, world, device)
@@ -147,7 +147,7 @@ def main():
             "config": {"workload": "reference default scene (main.cu:73-195), 1920x1080, 64 spp, depth 5, seed 0",
                        "math_mode": args.math, "partition": "%d contiguous row tiles + in-place all-gather" % world,
                        "flops_per_sample": fps},
-            "roofline": {"bound": "valu_fp32", "kernel": "render_fast_kernel" if args.math == "fast" else "render_parity_kernel",
+            "roofline": {"bound": "valu_fp32", "kernel": {"fast": "render_fast_kernel", "scalar": "render_fast_kernel", "lds": "render_fast_tiled_kernel", "parity": "render_parity_kernel"}[args.math],
                          "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": None,
                          "kernel_ms": kernel_ms, "kernel_msamples_per_s": tile_samples / kernel_ms / 1e3},

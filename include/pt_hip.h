@@ -50,7 +50,10 @@ typedef struct pt_prim {
 /* Math mode of pt_render. */
 enum {
     PT_MATH_PARITY = 0, /* reference operation order, IEEE div/sqrt, no FMA contraction */
-    PT_MATH_FAST = 1    /* same algorithm, FMA + v_rcp/v_rsq/v_sin/v_cos, restructured tests */
+    PT_MATH_FAST = 1,   /* same algorithm, FMA + v_rcp/v_rsq/v_sin/v_cos, restructured tests */
+    /* PT_MATH_FAST picks one of the next two by scene size; they can also be forced (same results bit for bit): */
+    PT_MATH_FAST_SCALAR = 2, /* primitive records fetched by scalar loads (small scenes: they stay in the scalar cache) */
+    PT_MATH_FAST_LDS = 3     /* primitive records staged chunk by chunk in LDS by the workgroup (large scenes) */
 };
 /* Framebuffer layout of pt_render. */
 enum {

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpt_hip.so")
 
 PT_PLANE, PT_CUBE, PT_CYLINDER, PT_SPHERE = 0, 1, 2, 3
-PT_MATH_PARITY, PT_MATH_FAST = 0, 1
+PT_MATH_PARITY, PT_MATH_FAST, PT_MATH_FAST_SCALAR, PT_MATH_FAST_LDS = 0, 1, 2, 3
 PT_FB_AOS, PT_FB_SOA = 0, 1
 
 

@@ -304,15 +304,32 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
         float rec[16];
         int32_t ft = 0;
         const int len = bake_fast(prims[k], fwd, inv, rec, &fs[k], &ft);
-        if (runs.empty() || runs.back().type != ft) {
-            while (fdata.size() % 16) fdata.push_back(0.0f);   // runs start on a 64-byte line
-            FRun r; r.type = ft; r.first = k; r.count = 0; r.offset = (int32_t)fdata.size();
+        // Runs start on a 64-byte line; a record never straddles a chunk boundary and a run never spans two chunks.
+        bool new_run = runs.empty() || runs.back().type != ft;
+        size_t start = fdata.size();
+        if (new_run) start = (start + 15) / 16 * 16;
+        if (start / FDATA_CHUNK != (start + len - 1) / FDATA_CHUNK) start = (start / FDATA_CHUNK + 1) * FDATA_CHUNK;
+        if (start % FDATA_CHUNK == 0) new_run = true;
+        fdata.resize(start, 0.0f);
+        if (new_run) {
+            FRun r; r.type = ft; r.first = k; r.count = 0; r.offset = (int32_t)start;
             runs.push_back(r);
         }
         runs.back().count++;
         fdata.insert(fdata.end(), rec, rec + len);
     }
     for (int pad = 0; pad < 16; pad++) fdata.push_back(0.0f);   // scalar loads may read past the last record
+    const int n_chunks = (int)((runs.back().offset + FDATA_CHUNK) / FDATA_CHUNK);
+    fdata.resize((size_t)n_chunks * FDATA_CHUNK + 16, 0.0f);     // whole chunks are staged
+    std::vector<int32_t> chunk_runs(n_chunks + 1, 0);
+    {
+        size_t r = 0;
+        for (int c = 0; c < n_chunks; c++) {
+            chunk_runs[c] = (int32_t)r;
+            while (r < runs.size() && runs[r].offset / FDATA_CHUNK == c) r++;
+        }
+        chunk_runs[n_chunks] = (int32_t)runs.size();
+    }
     std::vector<DMat> dm(n_mats);
     for (int i = 0; i < n_mats; i++) {
         std::memset(&dm[i], 0, sizeof(DMat));
@@ -331,6 +348,8 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
     UP(d_mats, dm, DMat)
     UP(d_fdata, fdata, float)
     UP(d_runs, runs, FRun)
+    UP(d_chunk_runs, chunk_runs, int32_t)
+    sc->n_chunks = n_chunks;
     UP(d_fshade, fs, FShade)
     sc->n_runs = (int)runs.size();
 #undef UP
@@ -345,6 +364,7 @@ int pt_scene_free(pt_scene* sc) {
     if (sc->d_mats) (void)hipFree(sc->d_mats);
     if (sc->d_fdata) (void)hipFree(sc->d_fdata);
     if (sc->d_runs) (void)hipFree(sc->d_runs);
+    if (sc->d_chunk_runs) (void)hipFree(sc->d_chunk_runs);
     if (sc->d_fshade) (void)hipFree(sc->d_fshade);
     delete sc;
     return 0;
@@ -387,9 +407,11 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     a.n_prims = sc->n_prims; a.n_mats = sc->n_mats;
     a.prims = sc->d_prims; a.mats = sc->d_mats;
     a.fdata = sc->d_fdata; a.runs = sc->d_runs; a.n_runs = sc->n_runs; a.fshade = sc->d_fshade;
+    a.chunk_runs = sc->d_chunk_runs; a.n_chunks = sc->n_chunks;
     a.fb = d_fb;
     if (cfg->math_mode == PT_MATH_PARITY) return ptk_render_parity(a, (hipStream_t)stream);
-    if (cfg->math_mode == PT_MATH_FAST) return ptk_render_fast(a, (hipStream_t)stream);
+    if (cfg->math_mode == PT_MATH_FAST || cfg->math_mode == PT_MATH_FAST_SCALAR || cfg->math_mode == PT_MATH_FAST_LDS)
+        return ptk_render_fast(a, cfg->math_mode, (hipStream_t)stream);
     return PT_FAIL("pt_render: unknown math_mode");
 }
 

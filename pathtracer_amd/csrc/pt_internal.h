@@ -43,6 +43,10 @@ struct DMat {
 //   FP_PLANE_GEN (16) : rows z, x, y of T^-1 (12) | xMin, yMin, xMax, yMax
 //   FP_SPHERE_WS (4)  : centre.xyz, radius^2   (L = s*R: tested in world space)
 //   FP_SPHERE, FP_CUBE, FP_CYLINDER (12): rows of T^-1
+// The float array is cut into chunks of FDATA_CHUNK floats; no record and no run crosses a chunk boundary, so a
+// workgroup can stage one chunk at a time in LDS (the LDS-tiled primitive loop for large scenes).
+constexpr int FDATA_CHUNK = 4096;
+
 struct FRun {
     int32_t type;     // FP_*
     int32_t first;    // index of the run's first primitive in the scene
@@ -73,6 +77,8 @@ struct pt_scene {
     float* d_fdata;        // fast-kernel intersection records
     FRun* d_runs;
     int n_runs;
+    int32_t* d_chunk_runs; // runs [d_chunk_runs[c], d_chunk_runs[c+1]) lie in chunk c
+    int n_chunks;
     FShade* d_fshade;
 };
 
@@ -93,13 +99,15 @@ struct RenderArgs {
     const float* fdata;
     const FRun* runs;
     int32_t n_runs;
+    const int32_t* chunk_runs;
+    int32_t n_chunks;
     const FShade* fshade;
     float* fb;
 };
 
 // Kernel launchers implemented in the .hip translation units.
 int ptk_render_parity(const RenderArgs& a, hipStream_t s);
-int ptk_render_fast(const RenderArgs& a, hipStream_t s);
+int ptk_render_fast(const RenderArgs& a, int variant, hipStream_t s);   // variant: PT_MATH_FAST (auto), _SCALAR, _LDS
 int ptk_raypath_batch(const pt_scene* sc, int prim, const float* o, const float* d, int n, int filter,
                       int32_t* dn, int32_t* h1, float* t1, float* p1, float* n1,
                       int32_t* h2, float* t2, float* p2, float* n2, hipStream_t s);

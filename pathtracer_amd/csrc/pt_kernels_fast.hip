@@ -195,15 +195,14 @@ PTD void test_cylinder(const float* R, V3 o, V3 d, int id, Best& b) {
     }
 }
 
-// getNearestIntersection (shapes.h:79-100): runs of same-kind primitives in scene
-// order; every index below is wave-uniform, so records arrive by scalar loads.
-PTD Best nearest(V3 o, V3 d, const float* __restrict__ fdata, const FRun* __restrict__ runs, int n_runs) {
-    Best b; b.t = __builtin_inff(); b.id = -8;
-    const float dd = dot(d, d);
-    const float idd = rcp(dd);
-    for (int r = 0; r < n_runs; r++) {
+// The loop of getNearestIntersection (shapes.h:82-98) over runs [r0, r1) of same-kind primitives, in scene order.
+// Record k of a run lives at base + run.offset + k*len; every index is wave-uniform.  `base` is the float array in
+// global memory (records then arrive by scalar loads) or an LDS image of one chunk of it.
+PTD void scan_runs(V3 o, V3 d, float dd, float idd, const float* __restrict__ base, const FRun* __restrict__ runs,
+                   int r0, int r1, Best& b) {
+    for (int r = r0; r < r1; r++) {
         const FRun run = runs[r];
-        const float* R = fdata + run.offset;
+        const float* R = base + run.offset;
         int id = run.first << 3;
         switch (run.type) {
             case FP_PLANE:
@@ -226,6 +225,15 @@ PTD Best nearest(V3 o, V3 d, const float* __restrict__ fdata, const FRun* __rest
                 break;
         }
     }
+}
+
+PTD Best best_none() { Best b; b.t = __builtin_inff(); b.id = -8; return b; }
+
+// getNearestIntersection (shapes.h:79-100), records by scalar loads.
+PTD Best nearest(V3 o, V3 d, const float* __restrict__ fdata, const FRun* __restrict__ runs, int n_runs) {
+    Best b = best_none();
+    const float dd = dot(d, d);
+    scan_runs(o, d, dd, rcp(dd), fdata, runs, 0, n_runs, b);
     return b;
 }
 
@@ -295,11 +303,8 @@ struct Path {
     int seg;
 };
 
-// One iteration of the tracePath loop (bsdf.h:78-166); true = continue.
-PTD bool path_step(Path& p, const float* __restrict__ fdata, const FRun* __restrict__ runs, int n_runs,
-                   const FShade* shade, const DMat* mats, int n_bounces, PhaseClock& clk) {
-    const Best b = nearest(p.o, p.d, fdata, runs, n_runs);
-    PHASE(clk, 1);
+// The tracePath loop body after the nearest hit is known (bsdf.h:84-165); true = continue.
+PTD bool path_shade(Path& p, const Best& b, const FShade* shade, const DMat* mats, int n_bounces, PhaseClock& clk) {
     if (b.id < 0) return false;
     const Surf s = surface(b, p.o, p.d, shade);
     const DMat& M = mats[s.material];
@@ -375,6 +380,14 @@ PTD bool path_step(Path& p, const float* __restrict__ fdata, const FRun* __restr
     return p.seg <= n_bounces;
 }
 
+// One iteration of the tracePath loop (bsdf.h:78-166); true = continue.
+PTD bool path_step(Path& p, const float* __restrict__ fdata, const FRun* __restrict__ runs, int n_runs,
+                   const FShade* shade, const DMat* mats, int n_bounces, PhaseClock& clk) {
+    const Best b = nearest(p.o, p.d, fdata, runs, n_runs);
+    PHASE(clk, 1);
+    return path_shade(p, b, shade, mats, n_bounces, clk);
+}
+
 }  // namespace ptf
 
 namespace {
@@ -388,6 +401,7 @@ struct FastCtx {
     const FShade* shade;   // LDS or global
     const DMat* mats;      // LDS or global
     float* pxt;            // LDS, this wave's [3][64]: i-0.5, H-j-0.5, K_px bits
+    float* stage;          // LDS, FDATA_CHUNK floats shared by the workgroup (LDS-tiled kernel only)
     PhaseClock clk;
 };
 
@@ -417,6 +431,30 @@ struct FastTracer {
     }
     static PTD bool step(Path& p, const RenderArgs& a, FastCtx& c) {
         return path_step(p, a.fdata, a.runs, a.n_runs, c.shade, c.mats, a.n_bounces, c.clk);
+    }
+    static PTD void idle(Path& p) {
+        p.o = v3(0.0f, 0.0f, 0.0f); p.d = v3(0.0f, 0.0f, 0.0f);
+        p.coef = v3(0.0f, 0.0f, 0.0f); p.contrib = v3(0.0f, 0.0f, 0.0f); p.key = 0; p.seg = 0;
+    }
+    // getNearestIntersection with the records staged through LDS: EVERY thread of the workgroup calls this
+    // (it contains barriers); lanes without a path carry a zero ray, which no test accepts.
+    static PTD Best nearest_block(const Path& p, const RenderArgs& a, FastCtx& c) {
+        Best b = best_none();
+        const float dd = dot(p.d, p.d);
+        const float idd = rcp(dd);
+        for (int chunk = 0; chunk < a.n_chunks; chunk++) {
+            const float4* src = reinterpret_cast<const float4*>(a.fdata + (size_t)chunk * FDATA_CHUNK);
+            float4* dst = reinterpret_cast<float4*>(c.stage);
+            __syncthreads();                                   // everyone is done with the previous chunk
+            for (int w = threadIdx.x; w < FDATA_CHUNK / 4; w += ptw::BLOCK) dst[w] = src[w];
+            __syncthreads();
+            scan_runs(p.o, p.d, dd, idd, c.stage - (size_t)chunk * FDATA_CHUNK, a.runs, a.chunk_runs[chunk], a.chunk_runs[chunk + 1], b);
+        }
+        PHASE(c.clk, 1);
+        return b;
+    }
+    static PTD bool shade(Path& p, const Best& b, const RenderArgs& a, FastCtx& c) {
+        return path_shade(p, b, c.shade, c.mats, a.n_bounces, c.clk);
     }
     static PTD void radiance(const Path& p, float rgb[3]) { rgb[0] = p.contrib.x; rgb[1] = p.contrib.y; rgb[2] = p.contrib.z; }
     static PTD void phase(FastCtx& c, int i) { PHASE(c.clk, i); (void)c; (void)i; }
@@ -451,6 +489,35 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, u
     ctx.clk.flush(threadIdx.x & 63);
 }
 
+// Large scenes: the workgroup stages the record array through LDS one chunk at a time and all four waves sweep
+// each chunk together.  Shading records stay in global memory (one gather per hit), materials go to LDS when
+// they fit.
+template <bool LDS_MATS>
+__global__ __launch_bounds__(ptw::BLOCK) void render_fast_tiled_kernel(RenderArgs a, uint32_t n_tiles) {
+    __shared__ float acc[ptw::WAVES_PER_BLOCK][192];
+    __shared__ float pxt[ptw::WAVES_PER_BLOCK][192];
+    __shared__ __attribute__((aligned(16))) float stage[FDATA_CHUNK];
+    __shared__ DMat lmats[LDS_MATS ? LDS_MAX_MATS : 1];
+    FastCtx ctx;
+    ctx.shade = a.fshade;
+    if (LDS_MATS) {
+        const uint32_t* gm = reinterpret_cast<const uint32_t*>(a.mats);
+        uint32_t* lm = reinterpret_cast<uint32_t*>(lmats);
+        for (uint32_t w = threadIdx.x; w < (uint32_t)a.n_mats * (sizeof(DMat) / 4); w += ptw::BLOCK) lm[w] = gm[w];
+        __syncthreads();
+        ctx.mats = lmats;
+    } else {
+        ctx.mats = a.mats;
+    }
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * ptw::WAVES_PER_BLOCK + wave;
+    ctx.pxt = pxt[wave];
+    ctx.stage = stage;
+    ctx.clk.start();
+    ptw::render_tile_blocksync<FastTracer>(a, tile, tile < n_tiles, acc[wave], ctx);
+    ctx.clk.flush(threadIdx.x & 63);
+}
+
 __global__ __launch_bounds__(256) void trace_fast_kernel(const float* __restrict__ fdata, const FRun* __restrict__ runs, int n_runs,
                                                          const FShade* __restrict__ shade, const DMat* __restrict__ mats,
                                                          const float* __restrict__ o, const float* __restrict__ d,
@@ -479,12 +546,21 @@ extern "C" int pt_dev_phase_cycles(unsigned long long* out, int reset) {
 }
 #endif
 
-int ptk_render_fast(const RenderArgs& a, hipStream_t s) {
+int ptk_render_fast(const RenderArgs& a, int variant, hipStream_t s) {
     const uint32_t npix = a.pix_end - a.pix_begin;
     if (npix == 0) return 0;
     const uint32_t n_tiles = (npix + 63u) / 64u;
     const uint32_t blocks = (n_tiles + ptw::WAVES_PER_BLOCK - 1) / ptw::WAVES_PER_BLOCK;
-    if (a.n_prims <= LDS_MAX_PRIMS && a.n_mats <= LDS_MAX_MATS)
+    // Measured on MI355X (profiles/r01/lds_vs_scalar.txt): the scalar-load loop beats the LDS-staged loop both on
+    // the 11-primitive scene (4.64 vs 6.66 ms) and on the 10 000-primitive scene (223 vs 249 ms), so PT_MATH_FAST
+    // always takes the scalar-load loop; the LDS-staged loop runs only when asked for.
+    const bool tiled = variant == PT_MATH_FAST_LDS;
+    if (tiled) {
+        if (a.n_mats <= LDS_MAX_MATS)
+            hipLaunchKernelGGL(render_fast_tiled_kernel<true>, dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+        else
+            hipLaunchKernelGGL(render_fast_tiled_kernel<false>, dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+    } else if (a.n_prims <= LDS_MAX_PRIMS && a.n_mats <= LDS_MAX_MATS)
         hipLaunchKernelGGL(render_fast_kernel<true>, dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
     else
         hipLaunchKernelGGL(render_fast_kernel<false>, dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);

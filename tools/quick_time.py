@@ -21,7 +21,7 @@ def main():
     prims, n, mats, nm = get_scene(name)
     sc = pt.Scene(prims, n, mats, nm)
     for mname in modes:
-        mm = pt.PT_MATH_PARITY if mname == "parity" else pt.PT_MATH_FAST
+        mm = {"parity": pt.PT_MATH_PARITY, "fast": pt.PT_MATH_FAST, "scalar": pt.PT_MATH_FAST_SCALAR, "lds": pt.PT_MATH_FAST_LDS}[mname]
         cfg = pt.make_config(w, h, spp, n_bounces=depth, math_mode=mm)
         out = sc.render(cfg)
         torch.cuda.synchronize()
