@@ -3,9 +3,10 @@
 
 A step is one render of the reference's default scene at 1920x1080, 64 spp,
 depth 5, seed 0 (BASELINE.json configs[1]) through pt_render of libpt_hip.so.
-With N GPUs (one process per GPU, torch.distributed "nccl" = RCCL) the frame is
-split into N contiguous row tiles and the framebuffer is all-gathered in place
-over xGMI inside the timed step, so total work is fixed: "strong" scaling.
+With N GPUs (one process per GPU, torch.distributed "nccl" = RCCL) rank r renders
+rows r, r+N, ... of the same frame and the tiles are all-gathered over xGMI inside
+the timed region (two frames in flight: the gather of frame k overlaps the render
+of frame k+1), so total work is fixed: "strong" scaling.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -71,6 +72,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--math", choices=["fast", "parity", "scalar", "lds"], default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: gather each frame before rendering the next")
     args = ap.parse_args()
 
     import torch
@@ -94,37 +96,59 @@ def main():
     prims, n, mats, nm = pt.default_scene()
     scene = pt.Scene(prims, n, mats, nm, device=local_rank)
     math_mode = {"fast": pt.PT_MATH_FAST, "parity": pt.PT_MATH_PARITY, "scalar": pt.PT_MATH_FAST_SCALAR, "lds": pt.PT_MATH_FAST_LDS}[args.math]
-    begin, end = multigpu.row_tile(HEIGHT, rank, world)
-    cfg = pt.make_config(WIDTH, HEIGHT, SPP, n_bounces=DEPTH, seed=SEED, row_begin=begin, row_end=end, math_mode=math_mode)
-    fb = multigpu.alloc_framebuffer(HEIGHT, WIDTH, world, device)
-    image = fb[:HEIGHT]
+    # rank r renders rows r, r+N, ... into a compact tile; all-gather + strided copy rebuild the image
+    my_rows = len(multigpu.rank_rows(HEIGHT, rank, world))
+    cfg = pt.make_config(WIDTH, HEIGHT, SPP, n_bounces=DEPTH, seed=SEED, row_begin=rank, row_end=HEIGHT, row_step=world,
+                         fb_compact=1, math_mode=math_mode)
+    # PT_BENCH_FORCE_OVERLAP=1 exercises the two-stream pipeline on one GPU (development aid)
+    overlap = (world > 1 or os.environ.get("PT_BENCH_FORCE_OVERLAP") == "1") and not args.no_overlap
+    frames = [multigpu.TiledFrame(HEIGHT, WIDTH, world, device) for _ in range(2 if overlap else 1)]
+    main_stream = torch.cuda.current_stream()
+    comm_stream = torch.cuda.Stream(device=device) if overlap else None
+    gathered_ev = [None, None]
 
-    def step():
-        if end > begin:
-            scene.render(cfg, out=image)
-        multigpu.gather_framebuffer(fb, rank, world)
+    def step(k, ev_pair=None):
+        """One frame: render this rank's rows, then gather.  With two frames in flight the gather of frame k runs on
+        a second stream while frame k+1 renders; frame k's buffers are reused by frame k+2 only after its gather."""
+        f = frames[k % len(frames)]
+        if overlap and gathered_ev[k % 2] is not None:
+            main_stream.wait_event(gathered_ev[k % 2])
+        if ev_pair:
+            ev_pair[0].record(main_stream)
+        if my_rows:
+            scene.render(cfg, out=f.local)
+        if ev_pair:
+            ev_pair[1].record(main_stream)
+        if not overlap:
+            f.gather()
+            return
+        done = torch.cuda.Event()
+        done.record(main_stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(done)
+            f.gather()
+            g = torch.cuda.Event()
+            g.record(comm_stream)
+            gathered_ev[k % 2] = g
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     fence()
     # Kernel time: HIP events on the stream pt_render launches on (torch's current stream), around the
     # render launch only, inside the timed region.
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record()
-        if end > begin:
-            scene.render(cfg, out=image)
-        ev[k][1].record()
-        multigpu.gather_framebuffer(fb, rank, world)
+        step(args.warmup + k, ev[k])
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    image = frames[(args.warmup + args.steps - 1) % len(frames)].image
 
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)
     if world > 1:
@@ -134,7 +158,7 @@ def main():
     if rank == 0:
         total_samples = WIDTH * HEIGHT * SPP
         fps = flops_per_sample()
-        tile_samples = (end - begin) * WIDTH * SPP
+        tile_samples = my_rows * WIDTH * SPP
         achieved = fps * tile_samples / (kernel_ms * 1e-3) / 1e12
         out = {
             "metric": "Msamples/sec at 1080p 64spp",
@@ -145,7 +169,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "reference default scene (main.cu:73-195), 1920x1080, 64 spp, depth 5, seed 0",
-                       "math_mode": args.math, "partition": "%d contiguous row tiles + in-place all-gather" % world,
+                       "math_mode": args.math, "partition": "rows r, r+%d, ... per rank, all-gather + strided copy%s" % (world, ", gather of frame k overlapped with render of frame k+1" if overlap else ""),
                        "flops_per_sample": fps},
             "roofline": {"bound": "valu_fp32", "kernel": {"fast": "render_fast_kernel", "scalar": "render_fast_kernel", "lds": "render_fast_tiled_kernel", "parity": "render_parity_kernel"}[args.math],
                          "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

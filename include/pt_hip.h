@@ -64,8 +64,11 @@ enum {
 /* config_t (main.cu:22-28) followed by the values the reference hard-codes:
  * n_samples (main.cu:54), n_bounces (bsdf.h:75), the RNG seed (main.cu:60 seeds
  * by pixel index only; seed selects an independent family of streams), and the
- * row tile [row_begin,row_end) this call renders (row 0 = bottom of the image,
- * main.cu:38). */
+ * rows this call renders: row_begin, row_begin + row_step, ... below row_end
+ * (row 0 = bottom of the image, main.cu:38; row_step 0 means 1).  With
+ * fb_compact = 0 a rendered row is written at its place in the full framebuffer;
+ * with fb_compact = 1 the k-th rendered row is written as row k of d_fb, which
+ * then only needs room for the rendered rows (interleaved multi-GPU tiles). */
 typedef struct pt_config {
     float camera_pos[3];
     int32_t max_x;
@@ -79,6 +82,8 @@ typedef struct pt_config {
     int32_t row_end;
     int32_t fb_layout;
     int32_t math_mode;
+    int32_t row_step;
+    int32_t fb_compact;
 } pt_config;
 
 typedef struct pt_scene pt_scene; /* opaque; owns the device copy of the primitive table */
@@ -105,8 +110,9 @@ int pt_synthetic_scene(int n_spheres, int n_cubes, uint32_t seed, pt_prim* prims
 float pt_focal_length(int nx, int ny, float v_height, float fov_deg);
 
 /* Replaces the render<<<blocks,threads>>> launch (main.cu:236).  d_fb is the
- * FULL max_x*max_y*3 float framebuffer in device memory; only pixels of rows
- * [row_begin,row_end) are written. */
+ * max_x*max_y*3 float framebuffer in device memory (or, with fb_compact, room
+ * for the rendered rows); only the rendered rows are written.  The image is
+ * bitwise the same however the rows are split over calls or GPUs. */
 int pt_render(const pt_scene* scene, const pt_config* cfg, float* d_fb, void* stream);
 
 /* Shape::getIntersections (filter != 0; shapes.h:60-75) or Shape::getRayPath

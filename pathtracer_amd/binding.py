@@ -38,6 +38,7 @@ class pt_config(C.Structure):
         ("focal_length", C.c_float), ("view_port_height", C.c_float),
         ("n_samples", C.c_int32), ("n_bounces", C.c_int32), ("seed", C.c_uint32),
         ("row_begin", C.c_int32), ("row_end", C.c_int32), ("fb_layout", C.c_int32), ("math_mode", C.c_int32),
+        ("row_step", C.c_int32), ("fb_compact", C.c_int32),
     ]
 
 
@@ -117,7 +118,7 @@ def synthetic_scene(n_spheres, n_cubes, seed=12345):
 
 
 def make_config(width, height, spp, n_bounces=5, seed=0, row_begin=0, row_end=None, camera=(0.0, 0.0, 0.0),
-                fb_layout=PT_FB_AOS, math_mode=PT_MATH_FAST):
+                fb_layout=PT_FB_AOS, math_mode=PT_MATH_FAST, row_step=1, fb_compact=0):
     """config_t of main.cu:234 with the reference's camera (origin, v_height 5, fov 45)."""
     cfg = pt_config()
     cfg.camera_pos[:] = camera
@@ -128,7 +129,14 @@ def make_config(width, height, spp, n_bounces=5, seed=0, row_begin=0, row_end=No
     cfg.row_begin = row_begin
     cfg.row_end = height if row_end is None else row_end
     cfg.fb_layout, cfg.math_mode = fb_layout, math_mode
+    cfg.row_step, cfg.fb_compact = row_step, fb_compact
     return cfg
+
+
+def rendered_rows(cfg):
+    """Number of rows a pt_render call with this config writes."""
+    step = cfg.row_step or 1
+    return max(0, (cfg.row_end - cfg.row_begin + step - 1) // step)
 
 
 def ppm_p3(fb):
@@ -178,10 +186,11 @@ class Scene:
     def render(self, cfg, out=None):
         """pt_render into a [H,W,3] (AoS) or [3,H,W] (SoA) float32 device tensor; rows outside the tile are untouched."""
         torch = _torch()
-        shape = (cfg.max_y, cfg.max_x, 3) if cfg.fb_layout == PT_FB_AOS else (3, cfg.max_y, cfg.max_x)
+        rows = rendered_rows(cfg) if cfg.fb_compact else cfg.max_y
+        shape = (rows, cfg.max_x, 3) if cfg.fb_layout == PT_FB_AOS else (3, rows, cfg.max_x)
         if out is None:
             out = torch.zeros(shape, dtype=torch.float32, device=self._dev())
-        assert out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == shape
+        assert out.is_contiguous() and out.dtype == torch.float32 and out.numel() >= rows * cfg.max_x * 3
         with torch.cuda.device(self.device):
             _check(lib.pt_render(self.h, C.byref(cfg), _ptr(out), _stream()))
         return out

@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -381,6 +382,8 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     if (cfg->row_begin < 0 || cfg->row_end > cfg->max_y || cfg->row_begin > cfg->row_end)
         return PT_FAIL("pt_render: row tile outside the image");
     if (cfg->fb_layout != PT_FB_AOS && cfg->fb_layout != PT_FB_SOA) return PT_FAIL("pt_render: unknown fb_layout");
+    if (cfg->row_step < 0) return PT_FAIL("pt_render: negative row_step");
+    if (cfg->fb_compact != 0 && cfg->fb_compact != 1) return PT_FAIL("pt_render: fb_compact must be 0 or 1");
     PT_CHECK(hipSetDevice(sc->device));
     RenderArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -401,8 +404,16 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     a.max_x = cfg->max_x; a.max_y = cfg->max_y;
     a.n_samples = cfg->n_samples; a.n_bounces = cfg->n_bounces;
     a.seed_hash = host_hash(cfg->seed + 0x9E3779B9u);
-    a.pix_begin = (uint32_t)cfg->row_begin * (uint32_t)cfg->max_x;
-    a.pix_end = (uint32_t)cfg->row_end * (uint32_t)cfg->max_x;
+    const int row_step = cfg->row_step == 0 ? 1 : cfg->row_step;
+    a.row_begin = cfg->row_begin; a.row_step = row_step;
+    a.n_rows = (cfg->row_end - cfg->row_begin + row_step - 1) / row_step;
+    a.n_lin = (uint32_t)a.n_rows * (uint32_t)cfg->max_x;
+    a.fb_compact = cfg->fb_compact;
+    // Pixels per wave: 64 when that still gives every wave slot of the chip (256 CUs x 32) about three tiles,
+    // fewer for small launches (row tiles of a multi-GPU frame) so that the chip stays full.  The image does not
+    // depend on this choice (pixel sums are exact fixed-point sums).
+    a.tile_log2 = a.n_lin >= 64u * 24576u ? 6 : (a.n_lin >= 32u * 24576u ? 5 : 4);
+    if (const char* e = std::getenv("PT_TILE_LOG2")) { const int v = std::atoi(e); if (v >= 4 && v <= 6) a.tile_log2 = v; }
     a.fb_layout = cfg->fb_layout;
     a.n_prims = sc->n_prims; a.n_mats = sc->n_mats;
     a.prims = sc->d_prims; a.mats = sc->d_mats;

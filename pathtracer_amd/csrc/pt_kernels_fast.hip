@@ -407,15 +407,12 @@ struct FastCtx {
 
 struct FastTracer {
     using Path = ptf::Path;
-    // Lane l prepares pixel l of the tile: jitter-free sample-plane coordinates
+    // Lane px prepares pixel px of the tile: jitter-free sample-plane coordinates
     // (main.cu:62) and the pixel's RNG key.
-    static PTD void prologue(const RenderArgs& a, FastCtx& c, uint32_t base, uint32_t lane) {
-        const uint32_t idx = base + lane;
-        const uint32_t j = idx / (uint32_t)a.max_x;
-        const uint32_t i = idx - j * (uint32_t)a.max_x;
-        c.pxt[lane] = (float)(int)i - 0.5f;
-        c.pxt[64 + lane] = (float)(a.max_y - (int)j) - 0.5f;
-        c.pxt[128 + lane] = __uint_as_float(rng_hash(idx ^ a.seed_hash));
+    static PTD void prologue(const RenderArgs& a, FastCtx& c, uint32_t px, const ptw::PixelRef& ref) {
+        c.pxt[px] = (float)ref.i - 0.5f;
+        c.pxt[64 + px] = (float)(a.max_y - ref.j) - 0.5f;
+        c.pxt[128 + px] = __uint_as_float(rng_hash(ref.index ^ a.seed_hash));
     }
     static PTD void start(Path& p, const RenderArgs& a, FastCtx& c, uint32_t px, uint32_t, uint32_t sample) {
         const uint32_t kpx = __float_as_uint(c.pxt[128 + px]);
@@ -462,7 +459,7 @@ struct FastTracer {
 
 template <bool LDS_TABLES>
 __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, uint32_t n_tiles) {
-    __shared__ float acc[ptw::WAVES_PER_BLOCK][192];
+    __shared__ ptw::WaveLds lds[ptw::WAVES_PER_BLOCK];
     __shared__ float pxt[ptw::WAVES_PER_BLOCK][192];
     __shared__ FShade lshade[LDS_TABLES ? LDS_MAX_PRIMS : 1];
     __shared__ DMat lmats[LDS_TABLES ? LDS_MAX_MATS : 1];
@@ -485,7 +482,7 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, u
     if (tile >= n_tiles) return;
     ctx.pxt = pxt[wave];
     ctx.clk.start();
-    ptw::render_tile<FastTracer>(a, tile, acc[wave], ctx);
+    ptw::render_tile<FastTracer>(a, tile, lds[wave], ctx);
     ctx.clk.flush(threadIdx.x & 63);
 }
 
@@ -494,7 +491,7 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, u
 // they fit.
 template <bool LDS_MATS>
 __global__ __launch_bounds__(ptw::BLOCK) void render_fast_tiled_kernel(RenderArgs a, uint32_t n_tiles) {
-    __shared__ float acc[ptw::WAVES_PER_BLOCK][192];
+    __shared__ ptw::WaveLds lds[ptw::WAVES_PER_BLOCK];
     __shared__ float pxt[ptw::WAVES_PER_BLOCK][192];
     __shared__ __attribute__((aligned(16))) float stage[FDATA_CHUNK];
     __shared__ DMat lmats[LDS_MATS ? LDS_MAX_MATS : 1];
@@ -514,7 +511,7 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_tiled_kernel(RenderArg
     ctx.pxt = pxt[wave];
     ctx.stage = stage;
     ctx.clk.start();
-    ptw::render_tile_blocksync<FastTracer>(a, tile, tile < n_tiles, acc[wave], ctx);
+    ptw::render_tile_blocksync<FastTracer>(a, tile, tile < n_tiles, lds[wave], ctx);
     ctx.clk.flush(threadIdx.x & 63);
 }
 
@@ -547,9 +544,8 @@ extern "C" int pt_dev_phase_cycles(unsigned long long* out, int reset) {
 #endif
 
 int ptk_render_fast(const RenderArgs& a, int variant, hipStream_t s) {
-    const uint32_t npix = a.pix_end - a.pix_begin;
-    if (npix == 0) return 0;
-    const uint32_t n_tiles = (npix + 63u) / 64u;
+    if (a.n_lin == 0) return 0;
+    const uint32_t n_tiles = (a.n_lin + (1u << a.tile_log2) - 1u) >> a.tile_log2;
     const uint32_t blocks = (n_tiles + ptw::WAVES_PER_BLOCK - 1) / ptw::WAVES_PER_BLOCK;
     // Measured on MI355X (profiles/r01/lds_vs_scalar.txt): the scalar-load loop beats the LDS-staged loop both on
     // the 11-primitive scene (4.64 vs 6.66 ms) and on the 10 000-primitive scene (223 vs 249 ms), so PT_MATH_FAST

@@ -11,12 +11,11 @@ struct ParityCtx {};
 
 struct ParityTracer {
     using Path = ptp::Path;
-    static __device__ __forceinline__ void prologue(const RenderArgs&, ParityCtx&, uint32_t, uint32_t) {}
-    static __device__ __forceinline__ void start(Path& p, const RenderArgs& a, ParityCtx&, uint32_t, uint32_t pixel_index, uint32_t sample) {
-        p.key = rng_key(a.seed_hash, pixel_index, sample);
-        const int j = (int)(pixel_index / (uint32_t)a.max_x);
-        const int i = (int)(pixel_index - (uint32_t)j * (uint32_t)a.max_x);
-        camera_ray(a, i, j, p.key, &p.o, &p.d);
+    static __device__ __forceinline__ void prologue(const RenderArgs&, ParityCtx&, uint32_t, const ptw::PixelRef&) {}
+    static __device__ __forceinline__ void start(Path& p, const RenderArgs& a, ParityCtx&, uint32_t, uint32_t lin, uint32_t sample) {
+        const ptw::PixelRef ref = ptw::pixel_of(a, lin);
+        p.key = rng_key(a.seed_hash, ref.index, sample);
+        camera_ray(a, ref.i, ref.j, p.key, &p.o, &p.d);
         p.coef = v3(1.0f, 1.0f, 1.0f);
         p.contrib = v3(0.0f, 0.0f, 0.0f);
         p.seg = 0;
@@ -31,12 +30,12 @@ struct ParityTracer {
 };
 
 __global__ __launch_bounds__(ptw::BLOCK) void render_parity_kernel(RenderArgs a, uint32_t n_tiles) {
-    __shared__ float acc[ptw::WAVES_PER_BLOCK][192];
+    __shared__ ptw::WaveLds lds[ptw::WAVES_PER_BLOCK];
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t tile = blockIdx.x * ptw::WAVES_PER_BLOCK + wave;
     if (tile >= n_tiles) return;
     ParityCtx ctx;
-    ptw::render_tile<ParityTracer>(a, tile, acc[wave], ctx);
+    ptw::render_tile<ParityTracer>(a, tile, lds[wave], ctx);
 }
 
 __device__ __forceinline__ V3 load3(const float* p, int i) { return v3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
@@ -108,9 +107,8 @@ __global__ void rng_kernel(uint32_t seed_hash, uint32_t pixel, uint32_t sample, 
 }  // namespace
 
 int ptk_render_parity(const RenderArgs& a, hipStream_t s) {
-    const uint32_t npix = a.pix_end - a.pix_begin;
-    if (npix == 0) return 0;
-    const uint32_t n_tiles = (npix + 63u) / 64u;
+    if (a.n_lin == 0) return 0;
+    const uint32_t n_tiles = (a.n_lin + (1u << a.tile_log2) - 1u) >> a.tile_log2;
     const uint32_t blocks = (n_tiles + ptw::WAVES_PER_BLOCK - 1) / ptw::WAVES_PER_BLOCK;
     hipLaunchKernelGGL(render_parity_kernel, dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
     PT_CHECK(hipGetLastError());

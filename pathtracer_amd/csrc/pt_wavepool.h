@@ -1,18 +1,20 @@
 // Wave-level sample pool shared by the render kernels.
 //
-// One wave64 owns a tile of 64 consecutive pixels (linear pixel index, so any
-// image width and any row range works) and the tile's 64 x spp samples form
-// its pool, ordered item w = sample*64 + pixel_in_tile.  Every loop iteration
+// The pixels of a launch are numbered row by row over the rows it renders
+// (row_begin, row_begin + row_step, ...).  One wave64 owns a tile of P = 16, 32
+// or 64 consecutive pixels of that numbering and the tile's P x spp samples form
+// its pool, ordered item w = sample*P + pixel_in_tile.  Every loop iteration
 // advances each lane's path by ONE segment.  Lanes whose path ended ask for new
 // work: a ballot of the asking lanes plus a prefix count (mbcnt) hands them the
-// next pool items in lane order, so all 64 lanes stay busy until the pool
-// drains.  The assignment depends only on the tile's own paths, never on
-// timing, so an image is reproducible run to run and independent of how rows
-// are split over GPUs.
+// next pool items in lane order, so all 64 lanes stay busy until the pool drains.
 //
 // A finished sample is added to its pixel's accumulator in LDS (the lane that
-// traced a sample is usually not the lane that owns the pixel); when the pool is
-// empty the wave divides by spp and writes the tile with coalesced stores.
+// traced a sample is usually not the lane that owns the pixel).  Accumulators
+// are 32.32 fixed-point integers, so a pixel's sum does not depend on the order
+// of the additions: the image is bitwise the same for every tile size, every
+// split of the rows over launches or GPUs, and every run.  When the pool is
+// empty the wave converts, divides by spp and writes the tile with coalesced
+// stores.
 #pragma once
 
 #include "pt_internal.h"
@@ -21,6 +23,13 @@ namespace ptw {
 
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int BLOCK = 64 * WAVES_PER_BLOCK;
+constexpr int ACC_WORDS = 64 * 3;   // 64-bit accumulators per wave
+
+// LDS of one wave: accumulators and where each tile pixel goes in the framebuffer.
+struct WaveLds {
+    unsigned long long acc[ACC_WORDS];
+    uint32_t out_px[64];
+};
 
 __device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 // Number of set bits of `mask` below this lane.
@@ -28,21 +37,72 @@ __device__ __forceinline__ unsigned prefix_count(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
+struct PixelRef {
+    int i, j;           // column, image row (row 0 = bottom, main.cu:38)
+    uint32_t index;     // j*max_x + i: the RNG stream's pixel key (main.cu:38,60)
+    uint32_t out;       // pixel slot in the framebuffer this launch writes
+};
+__device__ __forceinline__ PixelRef pixel_of(const RenderArgs& a, uint32_t lin) {
+    PixelRef r;
+    const uint32_t k = lin / (uint32_t)a.max_x;
+    r.i = (int)(lin - k * (uint32_t)a.max_x);
+    r.j = a.row_begin + (int)k * a.row_step;
+    r.index = (uint32_t)r.j * (uint32_t)a.max_x + (uint32_t)r.i;
+    r.out = a.fb_compact ? lin : r.index;
+    return r;
+}
+
+// x >= 0 as 32.32 fixed point (floor(x) in the high word, the fraction in the low word).
+__device__ __forceinline__ unsigned long long to_fixed(float x) {
+    const float fl = __builtin_floorf(x);
+    const unsigned lo = (unsigned)((x - fl) * 4294967296.0f);
+    const int hi = (int)fl;
+    return ((unsigned long long)(unsigned)hi << 32) | lo;
+}
+__device__ __forceinline__ float from_fixed(unsigned long long v) {
+    return (float)(int)(v >> 32) + (float)(unsigned)v * 2.3283064365386963e-10f;
+}
+
+__device__ __forceinline__ void add_sample(WaveLds& l, uint32_t px, const float rgb[3]) {
+    for (int c = 0; c < 3; c++)
+        __hip_atomic_fetch_add(&l.acc[px * 3 + c], to_fixed(rgb[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+// p_color = totalLight / n_samples (main.cu:67); consecutive floats of consecutive pixels leave together.
+__device__ __forceinline__ void store_tile(const RenderArgs& a, const WaveLds& l, uint32_t npx, unsigned lane) {
+    const float ns = (float)a.n_samples;
+    if (a.fb_layout == PT_FB_AOS) {
+        for (uint32_t f = lane; f < npx * 3u; f += 64u) {
+            const uint32_t px = (f * 43691u) >> 17;          // f / 3 for f < 2^16
+            a.fb[(size_t)l.out_px[px] * 3u + (f - px * 3u)] = from_fixed(l.acc[f]) / ns;
+        }
+    } else {
+        const size_t plane = a.fb_compact ? (size_t)a.n_lin : (size_t)a.max_x * (size_t)a.max_y;
+        if (lane < npx)
+            for (int c = 0; c < 3; c++) a.fb[c * plane + l.out_px[lane]] = from_fixed(l.acc[lane * 3 + c]) / ns;
+    }
+}
+
 // T supplies:  struct Path;
-//              static void prologue(const RenderArgs&, Ctx&, uint32_t base, uint32_t lane);   // once per tile
-//              static void start(Path&, const RenderArgs&, Ctx&, uint32_t px, uint32_t pixel_index, uint32_t sample);
+//              static void prologue(const RenderArgs&, Ctx&, uint32_t px, const PixelRef&);   // per tile pixel, by lane px
+//              static void start(Path&, const RenderArgs&, Ctx&, uint32_t px, uint32_t lin, uint32_t sample);
 //              static bool step(Path&, const RenderArgs&, Ctx&);     // true = path continues
 //              static void radiance(const Path&, float rgb[3]);
 //              static void phase(Ctx&, int);                          // development profiling hook, normally empty
 template <class T, class Ctx>
-__device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, float* acc /* LDS, 192 floats of this wave */, Ctx& ctx) {
+__device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, WaveLds& l, Ctx& ctx) {
     const unsigned lane = lane_id();
-    const uint32_t base = a.pix_begin + tile * 64u;
-    const uint32_t npx = min(64u, a.pix_end - base);
-    const uint32_t total = (uint32_t)a.n_samples * 64u;
+    const uint32_t lg = (uint32_t)a.tile_log2, P = 1u << lg;
+    const uint32_t lin_base = tile << lg;
+    const uint32_t npx = min(P, a.n_lin - lin_base);
+    const uint32_t total = (uint32_t)a.n_samples << lg;
 
-    acc[lane] = 0.0f; acc[lane + 64] = 0.0f; acc[lane + 128] = 0.0f;
-    T::prologue(a, ctx, base, lane);
+    l.acc[lane] = 0ull; l.acc[lane + 64] = 0ull; l.acc[lane + 128] = 0ull;
+    if (lane < npx) {
+        const PixelRef ref = pixel_of(a, lin_base + lane);
+        l.out_px[lane] = ref.out;
+        T::prologue(a, ctx, lane, ref);
+    }
     // One wave touches this LDS slice, in program order: no barrier needed.
 
     typename T::Path path;
@@ -55,10 +115,10 @@ __device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, 
             const uint32_t w = next + prefix_count(want);
             next += (uint32_t)__popcll(want);
             if (!active && w < total) {
-                const uint32_t px = w & 63u, smp = w >> 6;
+                const uint32_t px = w & (P - 1u), smp = w >> lg;
                 if (px < npx) {
                     my_px = px;
-                    T::start(path, a, ctx, px, base + px, smp);
+                    T::start(path, a, ctx, px, lin_base + px, smp);
                     active = true;
                 }
             }
@@ -74,28 +134,13 @@ __device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, 
             if (!go_on) {
                 float rgb[3];
                 T::radiance(path, rgb);
-                __hip_atomic_fetch_add(&acc[my_px * 3 + 0], rgb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add(&acc[my_px * 3 + 1], rgb[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add(&acc[my_px * 3 + 2], rgb[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                add_sample(l, my_px, rgb);
                 active = false;
             }
         }
         T::phase(ctx, 6);
     }
-
-    // p_color = totalLight / n_samples (main.cu:67), then the tile leaves as
-    // three fully coalesced 256-byte stores per layout.
-    const float ns = (float)a.n_samples;
-    const uint32_t nfl = npx * 3u;
-    if (a.fb_layout == PT_FB_AOS) {
-        float* out = a.fb + (size_t)base * 3u;
-        for (uint32_t f = lane; f < nfl; f += 64u) out[f] = acc[f] / ns;
-    } else {
-        const size_t plane = (size_t)a.max_x * (size_t)a.max_y;
-        if (lane < npx) {
-            for (int c = 0; c < 3; c++) a.fb[c * plane + base + lane] = acc[lane * 3 + c] / ns;
-        }
-    }
+    store_tile(a, l, npx, lane);
 }
 
 // The same pool, for tracers whose nearest-hit search is a WORKGROUP-wide operation (records staged through LDS
@@ -105,14 +150,19 @@ __device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, 
 //                           static Best nearest_block(const Path&, const RenderArgs&, Ctx&);   // contains barriers
 //                           static bool shade(Path&, const Best&, const RenderArgs&, Ctx&);    // true = path continues
 template <class T, class Ctx>
-__device__ __forceinline__ void render_tile_blocksync(const RenderArgs& a, uint32_t tile, bool tile_valid, float* acc, Ctx& ctx) {
+__device__ __forceinline__ void render_tile_blocksync(const RenderArgs& a, uint32_t tile, bool tile_valid, WaveLds& l, Ctx& ctx) {
     const unsigned lane = lane_id();
-    const uint32_t base = a.pix_begin + (tile_valid ? tile : 0u) * 64u;
-    const uint32_t npx = tile_valid ? min(64u, a.pix_end - base) : 0u;
-    const uint32_t total = tile_valid ? (uint32_t)a.n_samples * 64u : 0u;
+    const uint32_t lg = (uint32_t)a.tile_log2, P = 1u << lg;
+    const uint32_t lin_base = tile_valid ? tile << lg : 0u;
+    const uint32_t npx = tile_valid ? min(P, a.n_lin - lin_base) : 0u;
+    const uint32_t total = tile_valid ? (uint32_t)a.n_samples << lg : 0u;
 
-    acc[lane] = 0.0f; acc[lane + 64] = 0.0f; acc[lane + 128] = 0.0f;
-    if (tile_valid) T::prologue(a, ctx, base, lane);
+    l.acc[lane] = 0ull; l.acc[lane + 64] = 0ull; l.acc[lane + 128] = 0ull;
+    if (lane < npx) {
+        const PixelRef ref = pixel_of(a, lin_base + lane);
+        l.out_px[lane] = ref.out;
+        T::prologue(a, ctx, lane, ref);
+    }
 
     typename T::Path path;
     T::idle(path);
@@ -125,10 +175,10 @@ __device__ __forceinline__ void render_tile_blocksync(const RenderArgs& a, uint3
             const uint32_t w = next + prefix_count(want);
             next += (uint32_t)__popcll(want);
             if (!active && w < total) {
-                const uint32_t px = w & 63u, smp = w >> 6;
+                const uint32_t px = w & (P - 1u), smp = w >> lg;
                 if (px < npx) {
                     my_px = px;
-                    T::start(path, a, ctx, px, base + px, smp);
+                    T::start(path, a, ctx, px, lin_base + px, smp);
                     active = true;
                 }
             }
@@ -143,27 +193,14 @@ __device__ __forceinline__ void render_tile_blocksync(const RenderArgs& a, uint3
             if (!go_on) {
                 float rgb[3];
                 T::radiance(path, rgb);
-                __hip_atomic_fetch_add(&acc[my_px * 3 + 0], rgb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add(&acc[my_px * 3 + 1], rgb[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add(&acc[my_px * 3 + 2], rgb[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                add_sample(l, my_px, rgb);
                 active = false;
                 T::idle(path);
             }
         }
         T::phase(ctx, 6);
     }
-    if (!tile_valid) return;
-    const float ns = (float)a.n_samples;
-    const uint32_t nfl = npx * 3u;
-    if (a.fb_layout == PT_FB_AOS) {
-        float* out = a.fb + (size_t)base * 3u;
-        for (uint32_t f = lane; f < nfl; f += 64u) out[f] = acc[f] / ns;
-    } else {
-        const size_t plane = (size_t)a.max_x * (size_t)a.max_y;
-        if (lane < npx) {
-            for (int c = 0; c < 3; c++) a.fb[c * plane + base + lane] = acc[lane * 3 + c] / ns;
-        }
-    }
+    if (tile_valid) store_tile(a, l, npx, lane);
 }
 
 }  // namespace ptw

@@ -1,51 +1,58 @@
 """Row-tile data parallelism over the GPUs of one node.
 
-Every (pixel, sample) is independent and the RNG is keyed on the GLOBAL pixel
-index, so the image does not depend on how rows are split.  Rank r of `world`
-renders one contiguous row tile into its slice of a full-size framebuffer and a
-single in-place all-gather (RCCL over xGMI under the "nccl" backend) gives every
-rank the whole image.  The tile is padded to ceil(H/world) rows so that all
-ranks contribute equal-sized slices, as all_gather_into_tensor requires.
+Every (pixel, sample) is independent, the RNG is keyed on the GLOBAL pixel index
+and pixel sums are exact, so the image does not depend on how rows are split.
+Rank r of `world` renders the rows r, r + world, r + 2*world, ... (interleaved:
+rows through the glass spheres cost more than wall rows, so contiguous tiles
+would load the GPUs unevenly) into a compact local tile; one all-gather (RCCL
+over xGMI under the "nccl" backend) collects the tiles and a strided copy puts
+the rows back in image order.  Tiles are padded to ceil(H/world) rows so that
+all ranks contribute equal-sized slices, as all_gather_into_tensor requires.
 """
 import torch
 import torch.distributed as dist
 
 
 def tile_rows(height, world):
-    """Rows per rank (the last ranks may own fewer, or no, real rows)."""
+    """Rows per rank in the padded layout (the last ranks may own one real row fewer)."""
     return (height + world - 1) // world
 
 
-def row_tile(height, rank, world):
-    """[begin, end) of the rows rank renders."""
-    tr = tile_rows(height, world)
-    begin = min(height, rank * tr)
-    return begin, min(height, begin + tr)
+def rank_rows(height, rank, world):
+    """The image rows rank renders, as a range."""
+    return range(rank, height, world)
 
 
-def alloc_framebuffer(height, width, world, device):
-    """Full framebuffer padded to world * tile_rows rows, AoS [rows, W, 3] float32."""
-    return torch.zeros((tile_rows(height, world) * world, width, 3), dtype=torch.float32, device=device)
+class TiledFrame:
+    """Buffers of one frame in flight: the local compact tile, the gathered tiles and the assembled image."""
+
+    def __init__(self, height, width, world, device):
+        self.height, self.width, self.world = height, width, world
+        self.rows = tile_rows(height, world)
+        self.local = torch.zeros((self.rows, width, 3), dtype=torch.float32, device=device)
+        if world == 1:
+            self.gathered = self.local
+            self.image = self.local[:height]
+        else:
+            self.gathered = torch.zeros((world * self.rows, width, 3), dtype=torch.float32, device=device)
+            self.image = torch.zeros((height, width, 3), dtype=torch.float32, device=device)
+
+    def gather(self, group=None):
+        """All-gather the local tiles and put the rows back in image order."""
+        if self.world == 1:
+            return self.image
+        dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=group)
+        # gathered[r, k] is image row k*world + r
+        ordered = self.gathered.view(self.world, self.rows, self.width, 3).permute(1, 0, 2, 3).reshape(self.world * self.rows, self.width, 3)
+        self.image.copy_(ordered[:self.height])
+        return self.image
 
 
-def gather_framebuffer(fb, rank, world, group=None):
-    """In-place all-gather of the row tiles held in the padded framebuffer `fb`."""
-    if world == 1:
-        return fb
-    tr = fb.shape[0] // world
-    flat = fb.view(-1)
-    n = tr * fb.shape[1] * fb.shape[2]
-    dist.all_gather_into_tensor(flat, flat[rank * n:(rank + 1) * n], group=group)
-    return fb
-
-
-def render_tiled(render_rows, height, width, rank, world, fb=None, device="cpu", group=None):
-    """Renders this rank's tile with `render_rows(fb_view, row_begin, row_end)` — which must write rows
-    [row_begin,row_end) of the [height, W, 3] view it is given — then gathers.  Returns the [height, W, 3] image."""
-    if fb is None:
-        fb = alloc_framebuffer(height, width, world, device)
-    begin, end = row_tile(height, rank, world)
-    if end > begin:
-        render_rows(fb[:height], begin, end)
-    gather_framebuffer(fb, rank, world, group=group)
-    return fb[:height]
+def render_tiled(render_rows, height, width, rank, world, frame=None, device="cpu", group=None):
+    """Renders this rank's rows with `render_rows(local, row_begin, row_step)` — which must write image row
+    row_begin + k*row_step into local[k] — then gathers.  Returns the [height, W, 3] image."""
+    if frame is None:
+        frame = TiledFrame(height, width, world, device)
+    if rank < height:
+        render_rows(frame.local, rank, world)
+    return frame.gather(group=group)

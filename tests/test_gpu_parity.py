@@ -212,6 +212,25 @@ def test_render_is_deterministic_and_tiling_independent(torch, pt):
         c = pt.make_config(200, 120, 8, math_mode=mm, fb_layout=pt.PT_FB_SOA)
         soa = sc.render(c)
         assert torch.equal(soa.permute(1, 2, 0).contiguous(), a)
+        # interleaved rows (rank r takes rows r, r+N, ...), written in place and written compactly
+        for parts in (2, 3, 8):
+            out = torch.zeros_like(a)
+            for r in range(parts):
+                sc.render(pt.make_config(200, 120, 8, math_mode=mm, row_begin=r, row_step=parts), out=out)
+            assert torch.equal(a, out), (mm, parts, "interleaved in place")
+            for r in range(parts):
+                c = pt.make_config(200, 120, 8, math_mode=mm, row_begin=r, row_step=parts, fb_compact=1)
+                comp = sc.render(c)
+                assert comp.shape[0] == len(range(r, 120, parts))
+                assert torch.equal(comp, a[r::parts]), (mm, parts, "compact")
+        # pixels per wave (16, 32, 64) do not change a single bit: pixel sums are exact integer sums
+        import os
+        try:
+            for lg in ("4", "5", "6"):
+                os.environ["PT_TILE_LOG2"] = lg
+                assert torch.equal(sc.render(cfg), a), (mm, lg)
+        finally:
+            os.environ.pop("PT_TILE_LOG2", None)
 
 
 def test_render_edge_cases(torch, pt, oracle):

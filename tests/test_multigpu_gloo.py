@@ -34,9 +34,10 @@ def _worker(rank, world, port, height, width, spp, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sc = ob.Scene(*ob.default_scene())
 
-    def render_rows(view, begin, end):
-        cfg = ob.make_config(width, height, spp, row_begin=begin, row_end=end)
-        view[begin:end] = torch.from_numpy(sc.render(cfg, threads=2)[begin:end])
+    def render_rows(local, row_begin, row_step):
+        rows = np.arange(row_begin, height, row_step, dtype=np.int32)
+        full = sc.render(ob.make_config(width, height, spp), threads=2, rows=rows)
+        local[:len(rows)] = torch.from_numpy(full[rows])
 
     img = multigpu.render_tiled(render_rows, height, width, rank, world)
     q.put((rank, img.numpy().copy()))
@@ -66,8 +67,14 @@ def test_tile_arithmetic():
     from pathtracer_amd import multigpu
     for h in (1, 7, 135, 1080, 2160):
         for w in (1, 2, 3, 4, 8):
-            tiles = [multigpu.row_tile(h, r, w) for r in range(w)]
-            covered = [j for b, e in tiles for j in range(b, e)]
-            assert covered == list(range(h))
-            assert all(e - b <= multigpu.tile_rows(h, w) for b, e in tiles)
-    assert multigpu.row_tile(1080, 3, 8) == (405, 540)
+            rows = [list(multigpu.rank_rows(h, r, w)) for r in range(w)]
+            assert sorted(j for rr in rows for j in rr) == list(range(h))
+            assert all(len(rr) <= multigpu.tile_rows(h, w) for rr in rows)
+    assert list(multigpu.rank_rows(1080, 3, 8))[:3] == [3, 11, 19]
+
+
+def test_single_rank_frame_is_the_local_tile():
+    from pathtracer_amd import multigpu
+    f = multigpu.TiledFrame(5, 4, 1, "cpu")
+    f.local[:] = 1.0
+    assert f.gather() is f.image and f.image.shape == (5, 4, 3) and bool((f.image == 1.0).all())
