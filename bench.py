@@ -38,6 +38,18 @@ def flops_per_sample():
         return float(json.load(f)[FLOPS_KEY]["flops_per_sample"])
 
 
+def measured_traffic_bytes(kernel):
+    """HBM bytes per launch of the full-frame render kernel from the committed rocprofv3 --pmc passes
+    (profiles/r01/pmc_render_fast_d.json: WRITE_SIZE and FETCH_SIZE in KB, separate passes; FETCH_SIZE doubled
+    as the gfx950 counter reports half the bytes of wide reads).  None when no profile of that kernel is stored."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_render_fast_d.json")
+    if kernel != "render_fast_kernel" or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    return (d["write"]["per_dispatch"]["WRITE_SIZE"] + 2.0 * d["fetch"]["per_dispatch"]["FETCH_SIZE"]) * 1024.0
+
+
 def cpu_baseline(gpu_image):
     """The CPU oracle on every CPU_ROW_STEP-th row of the same frame, all host threads of this process's share.
     Also returns how far the GPU image is from the oracle on those rows."""
@@ -173,7 +185,8 @@ def main():
                        "flops_per_sample": fps},
             "roofline": {"bound": "valu_fp32", "kernel": {"fast": "render_fast_kernel", "scalar": "render_fast_kernel", "lds": "render_fast_tiled_kernel", "parity": "render_parity_kernel"}[args.math],
                          "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_VALU_PEAK_TFLOPS,
+                         "traffic": measured_traffic_bytes("render_fast_kernel" if args.math in ("fast", "scalar") else args.math) if world == 1 else None,
                          "kernel_ms": kernel_ms, "kernel_msamples_per_s": tile_samples / kernel_ms / 1e3},
         }
         if world == 1 and not args.no_cpu_baseline:

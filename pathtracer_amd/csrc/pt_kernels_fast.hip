@@ -23,12 +23,17 @@
 // Phases: 0 refill, 1 nearest, 2 surface + material fetch, 3 emissive/Beer/Fresnel/mode, 4 direction, 5 throughput +
 // roulette, 6 accumulate.  Not compiled into libpt_hip.so.
 #ifdef PT_PHASE_PROF
-__device__ unsigned long long g_phase_cycles[8];
+__device__ unsigned long long g_phase_cycles[16];   // [0..7] cycles, [8..15] cycles x active lanes at the stamp
 struct PhaseClock {
-    unsigned long long last, acc[8];
-    __device__ void start() { for (int i = 0; i < 8; i++) acc[i] = 0; last = __builtin_amdgcn_s_memtime(); }
-    __device__ void mark(int i) { const unsigned long long now = __builtin_amdgcn_s_memtime(); acc[i] += now - last; last = now; }
-    __device__ void flush(unsigned lane) { if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_phase_cycles[i], acc[i]); }
+    unsigned long long last, acc[8], lanes[8];
+    __device__ void start() { for (int i = 0; i < 8; i++) { acc[i] = 0; lanes[i] = 0; } last = __builtin_amdgcn_s_memtime(); }
+    __device__ void mark(int i) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        acc[i] += now - last; lanes[i] += (now - last) * (unsigned long long)__popcll(__ballot(1)); last = now;
+    }
+    __device__ void flush(unsigned lane) {
+        if (lane == 0) for (int i = 0; i < 8; i++) { atomicAdd(&g_phase_cycles[i], acc[i]); atomicAdd(&g_phase_cycles[8 + i], lanes[i]); }
+    }
 };
 #define PHASE(clk, i) (clk).mark(i)
 #else
@@ -205,9 +210,14 @@ PTD void scan_runs(V3 o, V3 d, float dd, float idd, const float* __restrict__ ba
         const float* R = base + run.offset;
         int id = run.first << 3;
         switch (run.type) {
-            case FP_PLANE:
-                for (int i = 0; i < run.count; i++, R += 12, id += 8) test_plane(R, o, d, id, b);
+            case FP_PLANE: {
+                int i = 0;
+#ifdef PT_UNROLL_PLANES
+                for (; i + 2 <= run.count; i += 2, R += 24, id += 16) { test_plane(R, o, d, id, b); test_plane(R + 12, o, d, id + 8, b); }
+#endif
+                for (; i < run.count; i++, R += 12, id += 8) test_plane(R, o, d, id, b);
                 break;
+            }
             case FP_SPHERE_WS:
                 for (int i = 0; i < run.count; i++, R += 4, id += 8) test_sphere_ws(R, o, d, dd, idd, id, b);
                 break;
@@ -537,8 +547,8 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(const float* __restrict
 #ifdef PT_PHASE_PROF
 extern "C" int pt_dev_phase_cycles(unsigned long long* out, int reset) {
     PT_CHECK(hipDeviceSynchronize());
-    PT_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 8 * sizeof(unsigned long long)));
-    if (reset) { unsigned long long z[8] = {0}; PT_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z))); }
+    PT_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(unsigned long long)));
+    if (reset) { unsigned long long z[16] = {0}; PT_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z))); }
     return 0;
 }
 #endif

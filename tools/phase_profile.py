@@ -19,12 +19,12 @@ hs = C.c_void_p()
 assert prof.pt_scene_upload(prims, n, mats, nm, 0, C.byref(hs)) == 0
 cfg = b.make_config(w, h, spp, n_bounces=depth)
 fb = torch.zeros((h, w, 3), device="cuda")
-buf = (C.c_ulonglong * 8)()
+buf = (C.c_ulonglong * 16)()
 assert prof.pt_render(hs, C.byref(cfg), C.c_void_p(fb.data_ptr()), None) == 0
 prof.pt_dev_phase_cycles(buf, 1)
 assert prof.pt_render(hs, C.byref(cfg), C.c_void_p(fb.data_ptr()), None) == 0
 prof.pt_dev_phase_cycles(buf, 1)
 names = ["refill", "nearest", "surface+material", "emissive/Beer/Fresnel/mode", "direction", "throughput+roulette", "accumulate", "-"]
-tot = float(sum(buf))
+tot = float(sum(buf[:8]))
 for k in range(7):
-    print("%-28s %6.2f %%" % (names[k], 100.0 * buf[k] / tot))
+    print("%-28s %6.2f %% of cycles, %5.1f %% of lanes active at the stamp" % (names[k], 100.0 * buf[k] / tot, 100.0 * buf[8 + k] / (64.0 * buf[k]) if buf[k] else 0.0))
