@@ -106,6 +106,12 @@ int pt_glass_grid_scene(int n, pt_prim* prims, pt_material* mats, int* n_mats);
  * primitive count (11 + n_spheres + n_cubes). */
 int pt_synthetic_scene(int n_spheres, int n_cubes, uint32_t seed, pt_prim* prims, pt_material* mats, int* n_mats);
 
+/* Scene description text -> the same tables the builders above fill (grammar in
+ * pathtracer_amd/csrc/pt_io.cpp; scenes/default.scene is main.cu:73-195 written
+ * in it).  Returns the primitive count, or -1 with the reason in pt_last_error().
+ * No counterpart in the reference, whose scene is compiled in (main.cu:71-198). */
+int pt_scene_parse(const char* text, pt_prim* prims, int cap_prims, pt_material* mats, int cap_mats, int* n_mats);
+
 /* Host-side focal length exactly as main.cu:229-232 computes it (integer nx/ny). */
 float pt_focal_length(int nx, int ny, float v_height, float fov_deg);
 
@@ -143,6 +149,12 @@ int pt_rng_draws(int device, uint32_t seed, uint32_t pixel, uint32_t sample, int
 /* PPM P3 text of a host AoS framebuffer exactly as main.cu:240-253 prints it.
  * Returns the byte count, or -1 if cap is too small. */
 long pt_ppm_p3(const float* fb, int nx, int ny, char* out, long cap);
+
+/* Binary writers beside the reference's ASCII PPM: P6 (8-bit, int(255.99*c)
+ * clamped to [0,255], rows top to bottom) and PFM (float32, rows bottom to top).
+ * Return the byte count, or -1 if cap is too small. */
+long pt_ppm_p6(const float* fb, int nx, int ny, unsigned char* out, long cap);
+long pt_pfm(const float* fb, int nx, int ny, unsigned char* out, long cap);
 
 const char* pt_last_error(void);
 const char* pt_version(void);

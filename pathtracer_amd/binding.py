@@ -70,6 +70,11 @@ def _load():
     L.pt_rng_draws.argtypes = [i32, u32, u32, u32, i32, vp, vp, vp]
     L.pt_ppm_p3.restype = C.c_long
     L.pt_ppm_p3.argtypes = [vp, i32, i32, C.c_char_p, C.c_long]
+    L.pt_ppm_p6.restype = C.c_long
+    L.pt_ppm_p6.argtypes = [vp, i32, i32, C.c_char_p, C.c_long]
+    L.pt_pfm.restype = C.c_long
+    L.pt_pfm.argtypes = [vp, i32, i32, C.c_char_p, C.c_long]
+    L.pt_scene_parse.argtypes = [C.c_char_p, C.POINTER(pt_prim), i32, C.POINTER(pt_material), i32, C.POINTER(i32)]
     return L
 
 
@@ -79,6 +84,7 @@ EXPORTS = [
     "pt_scene_upload", "pt_scene_free", "pt_scene_device", "pt_default_scene", "pt_glass_grid_scene",
     "pt_synthetic_scene", "pt_focal_length", "pt_render", "pt_raypath_batch", "pt_nearest_batch",
     "pt_trace_paths", "pt_rng_draws", "pt_ppm_p3", "pt_last_error", "pt_version",
+    "pt_scene_parse", "pt_ppm_p6", "pt_pfm",
 ]
 
 
@@ -149,6 +155,42 @@ def ppm_p3(fb):
     if n < 0:
         raise PtError("pt_ppm_p3: buffer too small")
     return buf.raw[:n]
+
+
+def parse_scene(text, max_prims=None, max_mats=None):
+    """Scene description text (see scenes/default.scene) -> (prims, n, mats, n_mats)."""
+    if isinstance(text, str):
+        text = text.encode()
+    max_prims = max_prims or max(1, text.count(b"\n") + 1)
+    max_mats = max_mats or max_prims
+    prims = (pt_prim * max_prims)()
+    mats = (pt_material * max_mats)()
+    nm = C.c_int(0)
+    n = lib.pt_scene_parse(text, prims, max_prims, mats, max_mats, C.byref(nm))
+    if n < 0:
+        raise PtError(lib.pt_last_error().decode(errors="replace").strip())
+    return prims, n, mats, nm.value
+
+
+def _write_image(fn, fb, bytes_per_pixel):
+    fb = np.ascontiguousarray(fb, np.float32)
+    h, w, _ = fb.shape
+    cap = 64 + h * w * bytes_per_pixel
+    buf = C.create_string_buffer(cap)
+    n = fn(fb.ctypes.data_as(C.c_void_p), w, h, buf, cap)
+    if n < 0:
+        raise PtError("image buffer too small")
+    return buf.raw[:n]
+
+
+def ppm_p6(fb):
+    """Binary PPM bytes of a host [H,W,3] framebuffer (clamped 8-bit)."""
+    return _write_image(lib.pt_ppm_p6, fb, 3)
+
+
+def pfm(fb):
+    """PFM bytes (float32, bottom row first) of a host [H,W,3] framebuffer."""
+    return _write_image(lib.pt_pfm, fb, 12)
 
 
 def _torch():

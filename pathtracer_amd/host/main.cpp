@@ -3,10 +3,12 @@
 // ASCII PPM (P3) on stdout with scanline progress on stderr.  Every literal of
 // the reference's main() is a flag here whose default is that literal:
 //   --width 800 --height 800 --spp 2000 --depth 5 --seed 0 --math fast
-//   --scene default|glass[N]|synthetic  --gpus 1  --stats
+//   --scene default|glass[N]|synthetic  --scene-file FILE  --format p3|p6|pfm  --gpus 1  --stats
 // Usage, as in the reference's readme:  pathtracer > out.ppm
 #include <chrono>
 #include <cmath>
+#include <fstream>
+#include <sstream>
 #include <cstring>
 #include <iostream>
 #include <string>
@@ -111,7 +113,7 @@ static int shapesFromTable(const std::vector<pt_prim>& prims, const std::vector<
 int main(int argc, char** argv) {
     int nx = 800, ny = 800, n_gpus = 1;
     render_options opt;                 // n_samples 2000, n_bounces 5 as in the reference
-    std::string scene_name = "default";
+    std::string scene_name = "default", scene_file, format = "p3";
     bool stats = false;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -123,6 +125,8 @@ int main(int argc, char** argv) {
         else if (a == "--seed") opt.seed = (unsigned)std::strtoul(next(), nullptr, 10);
         else if (a == "--math") opt.math_mode = std::string(next()) == "parity" ? PT_MATH_PARITY : PT_MATH_FAST;
         else if (a == "--scene") scene_name = next();
+        else if (a == "--scene-file") scene_file = next();
+        else if (a == "--format") format = next();
         else if (a == "--gpus") n_gpus = std::atoi(next());
         else if (a == "--stats") stats = true;
         else { std::cerr << "unknown flag " << a << "\n"; return 2; }
@@ -134,7 +138,23 @@ int main(int argc, char** argv) {
 
     /* Scene */
     std::vector<Shape*> scene;
-    if (scene_name == "default") {
+    if (format != "p3" && format != "p6" && format != "pfm") { std::cerr << "unknown format " << format << "\n"; return 2; }
+    if (!scene_file.empty()) {
+        std::ifstream f(scene_file);
+        if (!f) { std::cerr << "cannot open " << scene_file << "\n"; return 2; }
+        std::stringstream ss;
+        ss << f.rdbuf();
+        const std::string text = ss.str();
+        int cap = 1;
+        for (char c : text) cap += c == '\n';
+        std::vector<pt_prim> prims((size_t)cap);
+        std::vector<pt_material> mats((size_t)cap);
+        int nm = 0;
+        const int n = pt_scene_parse(text.c_str(), prims.data(), cap, mats.data(), cap, &nm);
+        if (n <= 0) { std::cerr << (n < 0 ? pt_last_error() : "scene file has no shapes") << "\n"; return 2; }
+        prims.resize((size_t)n);
+        shapesFromTable(prims, mats, scene);
+    } else if (scene_name == "default") {
         scene.resize(11);
         constructScene(scene.data());
     } else {
@@ -201,6 +221,16 @@ int main(int argc, char** argv) {
         const double samples = (double)num_pixels * opt.n_samples;
         std::clog << "{\"width\": " << nx << ", \"height\": " << ny << ", \"spp\": " << opt.n_samples << ", \"depth\": " << opt.n_bounces
                   << ", \"gpus\": " << n_gpus << ", \"kernel_ms\": " << worst << ", \"msamples_per_s\": " << samples / worst / 1e3 << "}\n";
+    }
+
+    if (format != "p3") {
+        const long cap = 64 + (long)num_pixels * 12;
+        std::vector<unsigned char> buf((size_t)cap);
+        const float* f = reinterpret_cast<const float*>(fb.data());
+        const long n = format == "p6" ? pt_ppm_p6(f, nx, ny, buf.data(), cap) : pt_pfm(f, nx, ny, buf.data(), cap);
+        std::cout.write(reinterpret_cast<const char*>(buf.data()), n);
+        for (Shape* s : scene) delete s;
+        return 0;
     }
 
     /* Output as PPM Image (main.cu:239-253) */

@@ -76,3 +76,44 @@ def test_bad_arguments_are_reported_not_fatal():
     assert rc != 0
     msg = binding.lib.pt_last_error().decode()
     assert msg.startswith("HIP error = ") and " at " in msg and "material index" in msg   # check_cuda shape, main.cu:14-15
+
+
+def test_scene_text_reproduces_the_default_scene_bitwise():
+    from pathtracer_amd import binding
+    text = open(os.path.join(ROOT, "scenes", "default.scene")).read()
+    p1, n1, m1, nm1 = binding.parse_scene(text)
+    p2, n2, m2, nm2 = binding.default_scene()
+    assert (n1, nm1) == (n2, nm2) == (11, 8)
+    assert bytes(p1)[: n1 * C.sizeof(binding.pt_prim)] == bytes(p2)
+    assert bytes(m1)[: nm1 * C.sizeof(binding.pt_material)] == bytes(m2)
+
+
+def test_scene_text_errors_and_options():
+    import pytest
+    from pathtracer_amd import binding
+    with pytest.raises(binding.PtError, match="scene line 2: shape needs a material"):
+        binding.parse_scene("material a albedo 1 1 1\nsphere b translate 0 0 -3\n")
+    with pytest.raises(binding.PtError, match="scene line 1: unknown statement"):
+        binding.parse_scene("torus a\n")
+    with pytest.raises(binding.PtError, match="expected a number"):
+        binding.parse_scene("material a albedo 1 x 1\n")
+    prims, n, mats, nm = binding.parse_scene("# c\nmaterial m IOR 1.3\ncylinder m rotate pi/4 0 0 1 scale 2 translate 1 2 3\nplane m\n")
+    assert (n, nm) == (2, 1) and abs(mats[0].IOR - 1.3) < 1e-7
+    t = np.array(prims[0].transform[:]).reshape(3, 4)
+    np.testing.assert_allclose(t[:, 3], [1, 2, 3])
+    np.testing.assert_allclose(t[:2, :2], 2 * np.array([[np.cos(np.pi / 4), -np.sin(np.pi / 4)], [np.sin(np.pi / 4), np.cos(np.pi / 4)]]), rtol=1e-6)
+    assert prims[1].bounds[0] == -np.finfo(np.float32).max and prims[1].bounds[2] == np.finfo(np.float32).max
+
+
+def test_binary_image_writers():
+    from pathtracer_amd import binding
+    rng = np.random.default_rng(3)
+    fb = (rng.random((4, 6, 3)) * 1.5 - 0.1).astype(np.float32)
+    p6 = binding.ppm_p6(fb)
+    head = b"P6\n6 4\n255\n"
+    assert p6.startswith(head)
+    want = np.clip((255.99 * fb[::-1].astype(np.float64)).astype(np.int64), 0, 255).astype(np.uint8)   # top row first
+    assert p6[len(head):] == want.tobytes()
+    pf = binding.pfm(fb)
+    head = b"PF\n6 4\n-1.0\n"
+    assert pf.startswith(head) and pf[len(head):] == fb.tobytes()

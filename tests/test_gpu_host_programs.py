@@ -44,3 +44,17 @@ def test_host_program_matches_library_render_and_reference_ppm_format():
 def test_host_program_rejects_bad_arguments():
     r = subprocess.run([_need("pathtracer"), "--gpus", "99"], capture_output=True, timeout=60)
     assert r.returncode == 2
+
+
+def test_host_program_scene_file_and_binary_formats():
+    import pathtracer_amd as pt
+    scene_file = os.path.join(ROOT, "scenes", "default.scene")
+    args = ["--width", "64", "--height", "48", "--spp", "4", "--math", "parity"]
+    a = subprocess.run([_need("pathtracer")] + args, capture_output=True, timeout=120)
+    b = subprocess.run([_need("pathtracer")] + args + ["--scene-file", scene_file], capture_output=True, timeout=120)
+    assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout      # the text scene IS the default scene
+    img = pt.Scene(*pt.default_scene()).render(pt.make_config(64, 48, 4, math_mode=pt.PT_MATH_PARITY)).cpu().numpy()
+    p6 = subprocess.run([_need("pathtracer")] + args + ["--format", "p6"], capture_output=True, timeout=120)
+    assert p6.returncode == 0 and p6.stdout == pt.ppm_p6(img)
+    pf = subprocess.run([_need("pathtracer")] + args + ["--format", "pfm"], capture_output=True, timeout=120)
+    assert pf.returncode == 0 and pf.stdout == pt.pfm(img)
