@@ -409,11 +409,13 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     a.n_rows = (cfg->row_end - cfg->row_begin + row_step - 1) / row_step;
     a.n_lin = (uint32_t)a.n_rows * (uint32_t)cfg->max_x;
     a.fb_compact = cfg->fb_compact;
-    // Pixels per wave: 64 when that still gives every wave slot of the chip (256 CUs x 32) about three tiles,
-    // fewer for small launches (row tiles of a multi-GPU frame) so that the chip stays full.  The image does not
-    // depend on this choice (pixel sums are exact fixed-point sums).
-    a.tile_log2 = a.n_lin >= 64u * 24576u ? 6 : (a.n_lin >= 32u * 24576u ? 5 : 4);
-    if (const char* e = std::getenv("PT_TILE_LOG2")) { const int v = std::atoi(e); if (v >= 4 && v <= 6) a.tile_log2 = v; }
+    // Pixels per wave.  Small tiles even out the end of the launch (a wave lives for about P*spp*2.4/64 loop
+    // iterations and the chip holds 8192 waves), large tiles amortise each wave's drain phase; measured on the
+    // 1080p frame and its interleaved row sets: 32 is best from 1.5 Mpixel, 16 from 0.2 Mpixel, 8 below, 64 only
+    // for frames several times 1080p.  The image does not depend on this choice (pixel sums are exact
+    // fixed-point sums).
+    a.tile_log2 = a.n_lin >= 6000000u ? 6 : (a.n_lin >= 1500000u ? 5 : (a.n_lin >= 200000u ? 4 : 3));
+    if (const char* e = std::getenv("PT_TILE_LOG2")) { const int v = std::atoi(e); if (v >= 2 && v <= 6) a.tile_log2 = v; }
     a.fb_layout = cfg->fb_layout;
     a.n_prims = sc->n_prims; a.n_mats = sc->n_mats;
     a.prims = sc->d_prims; a.mats = sc->d_mats;

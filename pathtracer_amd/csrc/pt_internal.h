@@ -94,7 +94,7 @@ struct RenderArgs {
     int32_t row_begin, row_step, n_rows;   // rendered rows: row_begin + k*row_step, k in [0, n_rows)
     uint32_t n_lin;                        // n_rows * max_x: pixels of this launch, numbered row by row
     int32_t fb_compact;                    // rendered row k is stored as row k (1) or at its image row (0)
-    int32_t tile_log2;                     // pixels per wave tile = 1 << tile_log2 (4..6)
+    int32_t tile_log2;                     // pixels per wave tile = 1 << tile_log2 (2..6)
     int32_t fb_layout;
     int32_t n_prims, n_mats;
     const DPrim* prims;

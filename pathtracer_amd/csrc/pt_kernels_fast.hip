@@ -63,9 +63,17 @@ PTD float min3(float a, float b, float c) { return __builtin_fminf(a, __builtin_
 PTD V3 unit(V3 a) { return a * rsq(dot(a, a)); }
 // Unit vector that leaves the zero vector alone (Eigen's normalized()).
 PTD V3 unit_or_zero(V3 a) { float n = dot(a, a); return n > 0.0f ? a * rsq(n) : a; }
+// Scene data that every lane reads at the same, wave-uniform address is read through pointers to the constant
+// address space: such loads are scalar loads (one fetch per wave, operands in SGPRs) whatever else the kernel
+// writes to global memory.  The LDS-staged loop passes plain pointers into its LDS image instead.
+typedef const float __attribute__((address_space(4)))* KFloatP;
+typedef const int32_t __attribute__((address_space(4)))* KIntP;
+PTD KFloatP as_constant(const float* p) { return (KFloatP)p; }
+PTD KIntP as_constant(const FRun* p) { return (KIntP)p; }
+
 // row . (p, 1)
-PTD float row_point(const float* r, V3 p) { return __builtin_fmaf(r[0], p.x, __builtin_fmaf(r[1], p.y, __builtin_fmaf(r[2], p.z, r[3]))); }
-PTD float row_vec(const float* r, V3 p) { return __builtin_fmaf(r[0], p.x, __builtin_fmaf(r[1], p.y, r[2] * p.z)); }
+template <class RP> PTD float row_point(RP r, V3 p) { return __builtin_fmaf(r[0], p.x, __builtin_fmaf(r[1], p.y, __builtin_fmaf(r[2], p.z, r[3]))); }
+template <class RP> PTD float row_vec(RP r, V3 p) { return __builtin_fmaf(r[0], p.x, __builtin_fmaf(r[1], p.y, r[2] * p.z)); }
 
 // ---- counter RNG: identical integer streams to the parity-order kernels ------
 PTD uint32_t rng_hash(uint32_t x) {
@@ -90,7 +98,7 @@ struct Best {
 // primitive index on ties, as getNearestIntersection does (shapes.h:93).
 
 // Plane with the bounds folded into rows x', y' (record: z row | x' row | y' row).
-PTD void test_plane(const float* R, V3 o, V3 d, int id, Best& b) {
+template <class RP> PTD void test_plane(RP R, V3 o, V3 d, int id, Best& b) {
     const float oz = row_point(R, o);
     const float dz = row_vec(R, d);
     const float t = -oz * rcp(dz);                 // dz == 0 gives inf/nan: every compare below fails
@@ -102,7 +110,7 @@ PTD void test_plane(const float* R, V3 o, V3 d, int id, Best& b) {
 }
 
 // Plane with explicit bounds (record: rows z, x, y | xMin, yMin, xMax, yMax).
-PTD void test_plane_gen(const float* R, V3 o, V3 d, int id, Best& b) {
+template <class RP> PTD void test_plane_gen(RP R, V3 o, V3 d, int id, Best& b) {
     const float oz = row_point(R, o);
     const float dz = row_vec(R, d);
     const float t = -oz * rcp(dz);
@@ -125,19 +133,19 @@ PTD void take_quadratic(float a, float ia, float h, float c, int id, Best& b) {
     b.id = ok ? id : b.id;
 }
 
-PTD void test_sphere_ws(const float* R, V3 o, V3 d, float dd, float idd, int id, Best& b) {
+template <class RP> PTD void test_sphere_ws(RP R, V3 o, V3 d, float dd, float idd, int id, Best& b) {
     const V3 oc = o - v3(R[0], R[1], R[2]);
     take_quadratic(dd, idd, dot(oc, d), dot(oc, oc) - R[3], id, b);
 }
 
-PTD void test_sphere(const float* R, V3 o, V3 d, int id, Best& b) {
+template <class RP> PTD void test_sphere(RP R, V3 o, V3 d, int id, Best& b) {
     const V3 ol = v3(row_point(R, o), row_point(R + 4, o), row_point(R + 8, o));
     const V3 dl = v3(row_vec(R, d), row_vec(R + 4, d), row_vec(R + 8, d));
     const float a = dot(dl, dl);
     take_quadratic(a, rcp(a), dot(dl, ol), dot(ol, ol) - 0.25f, id, b);
 }
 
-PTD void test_cube(const float* R, V3 o, V3 d, int id, Best& b) {
+template <class RP> PTD void test_cube(RP R, V3 o, V3 d, int id, Best& b) {
     const V3 ol = v3(row_point(R, o), row_point(R + 4, o), row_point(R + 8, o));
     const V3 dl = v3(row_vec(R, d), row_vec(R + 4, d), row_vec(R + 8, d));
     const float ix = rcp(dl.x), iy = rcp(dl.y), iz = rcp(dl.z);
@@ -159,7 +167,7 @@ PTD void test_cube(const float* R, V3 o, V3 d, int id, Best& b) {
 }
 
 // Cylinder: the case analysis of shapes.h:231-318 in local space.
-PTD void test_cylinder(const float* R, V3 o, V3 d, int id, Best& b) {
+template <class RP> PTD void test_cylinder(RP R, V3 o, V3 d, int id, Best& b) {
     const V3 ol = v3(row_point(R, o), row_point(R + 4, o), row_point(R + 8, o));
     const V3 dl = v3(row_vec(R, d), row_vec(R + 4, d), row_vec(R + 8, d));
     const float a = __builtin_fmaf(dl.x, dl.x, dl.y * dl.y);
@@ -203,11 +211,12 @@ PTD void test_cylinder(const float* R, V3 o, V3 d, int id, Best& b) {
 // The loop of getNearestIntersection (shapes.h:82-98) over runs [r0, r1) of same-kind primitives, in scene order.
 // Record k of a run lives at base + run.offset + k*len; every index is wave-uniform.  `base` is the float array in
 // global memory (records then arrive by scalar loads) or an LDS image of one chunk of it.
-PTD void scan_runs(V3 o, V3 d, float dd, float idd, const float* __restrict__ base, const FRun* __restrict__ runs,
-                   int r0, int r1, Best& b) {
+template <class RP>
+PTD void scan_runs(V3 o, V3 d, float dd, float idd, RP base, KIntP runs, int r0, int r1, Best& b) {
     for (int r = r0; r < r1; r++) {
-        const FRun run = runs[r];
-        const float* R = base + run.offset;
+        FRun run;
+        run.type = runs[4 * r]; run.first = runs[4 * r + 1]; run.count = runs[4 * r + 2]; run.offset = runs[4 * r + 3];
+        RP R = base + run.offset;
         int id = run.first << 3;
         switch (run.type) {
             case FP_PLANE: {
@@ -243,7 +252,7 @@ PTD Best best_none() { Best b; b.t = __builtin_inff(); b.id = -8; return b; }
 PTD Best nearest(V3 o, V3 d, const float* __restrict__ fdata, const FRun* __restrict__ runs, int n_runs) {
     Best b = best_none();
     const float dd = dot(d, d);
-    scan_runs(o, d, dd, rcp(dd), fdata, runs, 0, n_runs, b);
+    scan_runs(o, d, dd, rcp(dd), as_constant(fdata), as_constant(runs), 0, n_runs, b);
     return b;
 }
 
@@ -455,7 +464,7 @@ struct FastTracer {
             __syncthreads();                                   // everyone is done with the previous chunk
             for (int w = threadIdx.x; w < FDATA_CHUNK / 4; w += ptw::BLOCK) dst[w] = src[w];
             __syncthreads();
-            scan_runs(p.o, p.d, dd, idd, c.stage - (size_t)chunk * FDATA_CHUNK, a.runs, a.chunk_runs[chunk], a.chunk_runs[chunk + 1], b);
+            scan_runs(p.o, p.d, dd, idd, (const float*)c.stage - (size_t)chunk * FDATA_CHUNK, as_constant(a.runs), a.chunk_runs[chunk], a.chunk_runs[chunk + 1], b);
         }
         PHASE(c.clk, 1);
         return b;

@@ -1,8 +1,8 @@
 // Wave-level sample pool shared by the render kernels.
 //
 // The pixels of a launch are numbered row by row over the rows it renders
-// (row_begin, row_begin + row_step, ...).  One wave64 owns a tile of P = 16, 32
-// or 64 consecutive pixels of that numbering and the tile's P x spp samples form
+// (row_begin, row_begin + row_step, ...).  One wave64 owns a tile of P = 4 .. 64
+// consecutive pixels of that numbering and the tile's P x spp samples form
 // its pool, ordered item w = sample*P + pixel_in_tile.  Every loop iteration
 // advances each lane's path by ONE segment.  Lanes whose path ended ask for new
 // work: a ballot of the asking lanes plus a prefix count (mbcnt) hands them the

@@ -223,10 +223,10 @@ def test_render_is_deterministic_and_tiling_independent(torch, pt):
                 comp = sc.render(c)
                 assert comp.shape[0] == len(range(r, 120, parts))
                 assert torch.equal(comp, a[r::parts]), (mm, parts, "compact")
-        # pixels per wave (16, 32, 64) do not change a single bit: pixel sums are exact integer sums
+        # pixels per wave (4 .. 64) do not change a single bit: pixel sums are exact integer sums
         import os
         try:
-            for lg in ("4", "5", "6"):
+            for lg in ("2", "3", "4", "5", "6"):
                 os.environ["PT_TILE_LOG2"] = lg
                 assert torch.equal(sc.render(cfg), a), (mm, lg)
         finally:
