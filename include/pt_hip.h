@@ -50,10 +50,12 @@ typedef struct pt_prim {
 /* Math mode of pt_render. */
 enum {
     PT_MATH_PARITY = 0, /* reference operation order, IEEE div/sqrt, no FMA contraction */
-    PT_MATH_FAST = 1,   /* same algorithm, FMA + v_rcp/v_rsq/v_sin/v_cos, restructured tests */
-    /* PT_MATH_FAST picks one of the next two by scene size; they can also be forced (same results bit for bit): */
-    PT_MATH_FAST_SCALAR = 2, /* primitive records fetched by scalar loads (small scenes: they stay in the scalar cache) */
-    PT_MATH_FAST_LDS = 3     /* primitive records staged chunk by chunk in LDS by the workgroup (large scenes) */
+    PT_MATH_FAST = 1,   /* same algorithm, FMA + v_rcp/v_rsq/v_sin/v_cos, restructured tests; scenes with
+                         * 32 or more finite primitives are searched through a bounding-volume hierarchy
+                         * (same nearest hit as the loop of shapes.h:82-98, lowest index on ties) */
+    /* The loop over ALL primitives, in its two forms (same results bit for bit): */
+    PT_MATH_FAST_SCALAR = 2, /* primitive records fetched by scalar loads */
+    PT_MATH_FAST_LDS = 3     /* primitive records staged chunk by chunk in LDS by the workgroup */
 };
 /* Framebuffer layout of pt_render. */
 enum {
@@ -93,6 +95,10 @@ typedef struct pt_scene pt_scene; /* opaque; owns the device copy of the primiti
 int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, int n_mats, int device, pt_scene** out);
 int pt_scene_free(pt_scene* scene);
 int pt_scene_device(const pt_scene* scene);
+/* Nodes of the scene's bounding-volume hierarchy (0 = the scene has none: every
+ * primitive is tested for every ray).  No counterpart in the reference, whose
+ * getNearestIntersection always loops over all objects (shapes.h:82). */
+int pt_scene_bvh_nodes(const pt_scene* scene);
 
 /* The reference's default scene as data (main.cu:73-195): writes 11 primitives
  * and 8 materials; returns the primitive count. */

@@ -63,6 +63,7 @@ def _load():
     L.pt_scene_upload.argtypes = [C.POINTER(pt_prim), i32, C.POINTER(pt_material), i32, i32, C.POINTER(vp)]
     L.pt_scene_free.argtypes = [vp]
     L.pt_scene_device.argtypes = [vp]
+    L.pt_scene_bvh_nodes.argtypes = [vp]
     L.pt_render.argtypes = [vp, C.POINTER(pt_config), vp, vp]
     L.pt_raypath_batch.argtypes = [vp, i32, vp, vp, i32, i32] + [vp] * 9 + [vp]
     L.pt_nearest_batch.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
@@ -81,7 +82,7 @@ def _load():
 lib = _load()
 
 EXPORTS = [
-    "pt_scene_upload", "pt_scene_free", "pt_scene_device", "pt_default_scene", "pt_glass_grid_scene",
+    "pt_scene_upload", "pt_scene_free", "pt_scene_device", "pt_scene_bvh_nodes", "pt_default_scene", "pt_glass_grid_scene",
     "pt_synthetic_scene", "pt_focal_length", "pt_render", "pt_raypath_batch", "pt_nearest_batch",
     "pt_trace_paths", "pt_rng_draws", "pt_ppm_p3", "pt_last_error", "pt_version",
     "pt_scene_parse", "pt_ppm_p6", "pt_pfm",
@@ -224,6 +225,11 @@ class Scene:
 
     def _dev(self):
         return _torch().device("cuda", self.device)
+
+    @property
+    def bvh_nodes(self):
+        """Nodes of the bounding-volume hierarchy PT_MATH_FAST searches (0 = none, every primitive is tested)."""
+        return lib.pt_scene_bvh_nodes(self.h)
 
     def render(self, cfg, out=None):
         """pt_render into a [H,W,3] (AoS) or [3,H,W] (SoA) float32 device tensor; rows outside the tile are untouched."""

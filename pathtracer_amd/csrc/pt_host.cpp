@@ -4,6 +4,7 @@
 // camera constants must round exactly as a plain float evaluation does.
 #include "pt_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -207,6 +208,106 @@ int bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, float* rec, FSha
     }
 }
 
+// One primitive after baking: its fast-kernel record and kind, and its world-space bounding box.
+struct Baked {
+    float rec[16];
+    int len;
+    int32_t kind;
+    float lo[3], hi[3];
+};
+
+// World-space box of a finite primitive: the unit cube (which also bounds the unit cylinder) maps to
+// centre +- 0.5 * sum_j |L_ij|, the sphere of radius 0.5 to centre +- 0.5 * |row i of L|.
+void world_box(const pt_prim& p, const Aff& fwd, float* lo, float* hi) {
+    for (int i = 0; i < 3; i++) {
+        float h;
+        if (p.type == PT_SPHERE) h = 0.5f * len3(fwd.m[i][0], fwd.m[i][1], fwd.m[i][2]);
+        else h = 0.5f * (fabsf(fwd.m[i][0]) + fabsf(fwd.m[i][1]) + fabsf(fwd.m[i][2]));
+        lo[i] = fwd.m[i][3] - h; hi[i] = fwd.m[i][3] + h;
+    }
+}
+
+// Packs the records of primitives `ids` (ascending scene indices) into one float array cut into runs of
+// consecutive same-kind primitives.  Runs start on a 64-byte line; a record never straddles a chunk boundary and a
+// run never spans two chunks.  Returns the number of chunks.
+int pack_runs(const std::vector<Baked>& baked, const std::vector<int>& ids, std::vector<float>& fdata,
+              std::vector<FRun>& runs, std::vector<int32_t>& chunk_runs) {
+    int prev = -2;
+    for (int k : ids) {
+        const Baked& b = baked[k];
+        bool new_run = runs.empty() || runs.back().type != b.kind || k != prev + 1;
+        size_t start = fdata.size();
+        if (new_run) start = (start + 15) / 16 * 16;
+        if (start / FDATA_CHUNK != (start + b.len - 1) / FDATA_CHUNK) start = (start / FDATA_CHUNK + 1) * FDATA_CHUNK;
+        if (start % FDATA_CHUNK == 0) new_run = true;
+        fdata.resize(start, 0.0f);
+        if (new_run) {
+            FRun r; r.type = b.kind; r.first = k; r.count = 0; r.offset = (int32_t)start;
+            runs.push_back(r);
+        }
+        runs.back().count++;
+        fdata.insert(fdata.end(), b.rec, b.rec + b.len);
+        prev = k;
+    }
+    for (int pad = 0; pad < 16; pad++) fdata.push_back(0.0f);   // scalar loads may read past the last record
+    const int n_chunks = (int)((runs.back().offset + FDATA_CHUNK) / FDATA_CHUNK);
+    fdata.resize((size_t)n_chunks * FDATA_CHUNK + 16, 0.0f);     // whole chunks are staged
+    chunk_runs.assign(n_chunks + 1, 0);
+    size_t r = 0;
+    for (int c = 0; c < n_chunks; c++) {
+        chunk_runs[c] = (int32_t)r;
+        while (r < runs.size() && runs[r].offset / FDATA_CHUNK == c) r++;
+    }
+    chunk_runs[n_chunks] = (int32_t)runs.size();
+    return n_chunks;
+}
+
+// Median-split hierarchy over ids[lo, hi), appended to `nodes` in depth-first order.  Boxes are padded so that
+// the rounding of the kernels' slab test can never cull a primitive its own test would accept.
+void build_bvh(const std::vector<Baked>& baked, std::vector<int>& ids, int lo, int hi, std::vector<BNode>& nodes,
+               std::vector<BPrim>& bprims) {
+    const size_t me = nodes.size();
+    nodes.push_back(BNode());
+    float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = lo; i < hi; i++) {
+        const Baked& b = baked[ids[i]];
+        for (int a = 0; a < 3; a++) {
+            blo[a] = fminf(blo[a], b.lo[a]); bhi[a] = fmaxf(bhi[a], b.hi[a]);
+            const float c = 0.5f * (b.lo[a] + b.hi[a]);
+            clo[a] = fminf(clo[a], c); chi[a] = fmaxf(chi[a], c);
+        }
+    }
+    for (int a = 0; a < 3; a++) {
+        const float pad = 1e-4f * (1.0f + fmaxf(fabsf(blo[a]), fabsf(bhi[a])));
+        nodes[me].lo[a] = blo[a] - pad; nodes[me].hi[a] = bhi[a] + pad;
+    }
+    if (hi - lo <= BVH_LEAF_PRIMS) {
+        nodes[me].leaf = (int32_t)((bprims.size() << 3) | (size_t)(hi - lo));
+        std::sort(ids.begin() + lo, ids.begin() + hi);
+        for (int i = lo; i < hi; i++) {
+            const Baked& b = baked[ids[i]];
+            BPrim q;
+            std::memset(&q, 0, sizeof(q));
+            std::memcpy(q.rec, b.rec, 12 * sizeof(float));
+            q.kind = b.kind; q.id = ids[i] << 3;
+            bprims.push_back(q);
+        }
+    } else {
+        int axis = 0;
+        for (int a = 1; a < 3; a++) if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
+        const int mid = (lo + hi) / 2;
+        std::nth_element(ids.begin() + lo, ids.begin() + mid, ids.begin() + hi, [&](int x, int y) {
+            const float cx = baked[x].lo[axis] + baked[x].hi[axis], cy = baked[y].lo[axis] + baked[y].hi[axis];
+            return cx < cy || (cx == cy && x < y);
+        });
+        nodes[me].leaf = -1;
+        build_bvh(baked, ids, lo, mid, nodes, bprims);
+        build_bvh(baked, ids, mid, hi, nodes, bprims);
+    }
+    nodes[me].skip = (int32_t)nodes.size();
+}
+
 }  // namespace
 
 int pt_set_error(int code, const char* expr, const char* file, int line) {
@@ -293,8 +394,8 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
     PT_CHECK(hipSetDevice(device));
     std::vector<DPrim> dp(n_prims);
     std::vector<FShade> fs(n_prims);
-    std::vector<float> fdata;
-    std::vector<FRun> runs;
+    std::vector<Baked> baked(n_prims);
+    std::vector<int> all(n_prims), top, finite;
     for (int k = 0; k < n_prims; k++) {
         const Aff fwd = aff_load(prims[k].transform);
         const Aff inv = aff_inverse(fwd);
@@ -302,34 +403,25 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
         aff_store(fwd, dp[k].fwd);
         for (int j = 0; j < 4; j++) dp[k].bounds[j] = prims[k].bounds[j];
         dp[k].type = prims[k].type; dp[k].material = prims[k].material; dp[k].pad[0] = dp[k].pad[1] = 0;
-        float rec[16];
-        int32_t ft = 0;
-        const int len = bake_fast(prims[k], fwd, inv, rec, &fs[k], &ft);
-        // Runs start on a 64-byte line; a record never straddles a chunk boundary and a run never spans two chunks.
-        bool new_run = runs.empty() || runs.back().type != ft;
-        size_t start = fdata.size();
-        if (new_run) start = (start + 15) / 16 * 16;
-        if (start / FDATA_CHUNK != (start + len - 1) / FDATA_CHUNK) start = (start / FDATA_CHUNK + 1) * FDATA_CHUNK;
-        if (start % FDATA_CHUNK == 0) new_run = true;
-        fdata.resize(start, 0.0f);
-        if (new_run) {
-            FRun r; r.type = ft; r.first = k; r.count = 0; r.offset = (int32_t)start;
-            runs.push_back(r);
-        }
-        runs.back().count++;
-        fdata.insert(fdata.end(), rec, rec + len);
+        std::memset(&baked[k], 0, sizeof(Baked));
+        baked[k].len = bake_fast(prims[k], fwd, inv, baked[k].rec, &fs[k], &baked[k].kind);
+        world_box(prims[k], fwd, baked[k].lo, baked[k].hi);
+        all[k] = k;
+        (prims[k].type == PT_PLANE ? top : finite).push_back(k);
     }
-    for (int pad = 0; pad < 16; pad++) fdata.push_back(0.0f);   // scalar loads may read past the last record
-    const int n_chunks = (int)((runs.back().offset + FDATA_CHUNK) / FDATA_CHUNK);
-    fdata.resize((size_t)n_chunks * FDATA_CHUNK + 16, 0.0f);     // whole chunks are staged
-    std::vector<int32_t> chunk_runs(n_chunks + 1, 0);
-    {
-        size_t r = 0;
-        for (int c = 0; c < n_chunks; c++) {
-            chunk_runs[c] = (int32_t)r;
-            while (r < runs.size() && runs[r].offset / FDATA_CHUNK == c) r++;
+    std::vector<float> fdata, fdata_top;
+    std::vector<FRun> runs, runs_top;
+    std::vector<int32_t> chunk_runs, chunk_runs_top;
+    const int n_chunks = pack_runs(baked, all, fdata, runs, chunk_runs);
+    std::vector<BNode> bnodes;
+    std::vector<BPrim> bprims;
+    if ((int)finite.size() >= BVH_MIN_PRIMS) {
+        build_bvh(baked, finite, 0, (int)finite.size(), bnodes, bprims);
+        if (top.empty()) {   // the loop over the other primitives still wants one (empty) chunk to read
+            fdata_top.assign(FDATA_CHUNK + 16, 0.0f);
+        } else {
+            pack_runs(baked, top, fdata_top, runs_top, chunk_runs_top);
         }
-        chunk_runs[n_chunks] = (int32_t)runs.size();
     }
     std::vector<DMat> dm(n_mats);
     for (int i = 0; i < n_mats; i++) {
@@ -353,6 +445,14 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
     sc->n_chunks = n_chunks;
     UP(d_fshade, fs, FShade)
     sc->n_runs = (int)runs.size();
+    if (!bnodes.empty()) {
+        UP(d_bnodes, bnodes, BNode)
+        UP(d_bprims, bprims, BPrim)
+        UP(d_fdata_top, fdata_top, float)
+        if (!runs_top.empty()) { UP(d_runs_top, runs_top, FRun) }
+        sc->n_bnodes = (int)bnodes.size();
+        sc->n_runs_top = (int)runs_top.size();
+    }
 #undef UP
     *out = sc;
     return 0;
@@ -367,11 +467,16 @@ int pt_scene_free(pt_scene* sc) {
     if (sc->d_runs) (void)hipFree(sc->d_runs);
     if (sc->d_chunk_runs) (void)hipFree(sc->d_chunk_runs);
     if (sc->d_fshade) (void)hipFree(sc->d_fshade);
+    if (sc->d_bnodes) (void)hipFree(sc->d_bnodes);
+    if (sc->d_bprims) (void)hipFree(sc->d_bprims);
+    if (sc->d_fdata_top) (void)hipFree(sc->d_fdata_top);
+    if (sc->d_runs_top) (void)hipFree(sc->d_runs_top);
     delete sc;
     return 0;
 }
 
 int pt_scene_device(const pt_scene* sc) { return sc ? sc->device : -1; }
+int pt_scene_bvh_nodes(const pt_scene* sc) { return sc ? sc->n_bnodes : -1; }
 
 int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* stream) {
     if (!sc || !cfg || !d_fb) return PT_FAIL("pt_render: null argument");
@@ -421,6 +526,12 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     a.prims = sc->d_prims; a.mats = sc->d_mats;
     a.fdata = sc->d_fdata; a.runs = sc->d_runs; a.n_runs = sc->n_runs; a.fshade = sc->d_fshade;
     a.chunk_runs = sc->d_chunk_runs; a.n_chunks = sc->n_chunks;
+    if (sc->n_bnodes > 0 && cfg->math_mode == PT_MATH_FAST) {
+        // PT_MATH_FAST walks the hierarchy for the finite primitives and loops over the rest;
+        // PT_MATH_FAST_SCALAR and PT_MATH_FAST_LDS keep testing every primitive.
+        a.bnodes = sc->d_bnodes; a.bprims = sc->d_bprims; a.n_bnodes = sc->n_bnodes;
+        a.fdata = sc->d_fdata_top; a.runs = sc->d_runs_top; a.n_runs = sc->n_runs_top;
+    }
     a.fb = d_fb;
     if (cfg->math_mode == PT_MATH_PARITY) return ptk_render_parity(a, (hipStream_t)stream);
     if (cfg->math_mode == PT_MATH_FAST || cfg->math_mode == PT_MATH_FAST_SCALAR || cfg->math_mode == PT_MATH_FAST_LDS)

@@ -66,6 +66,27 @@ struct FShade {
     int32_t pad[2];
 };
 
+// Bounding-volume hierarchy over the finite primitives (everything but planes) of scenes with many of them.
+// Nodes are stored in depth-first order: the first child of an inner node is the next node, `skip` is the node
+// to go to when the box is missed or its subtree is finished (the node count ends the walk), so the walk needs no
+// stack.  A leaf owns `leaf & 7` consecutive BPrim records starting at `leaf >> 3`; inner nodes have leaf = -1.
+struct BNode {
+    float lo[3];
+    int32_t skip;
+    float hi[3];
+    int32_t leaf;
+};
+// One primitive as the hierarchy's leaves hold it: the same record the primitive loop reads (see above), its kind
+// and its scene index << 3.  64 bytes, fetched per lane.
+struct BPrim {
+    float rec[12];
+    int32_t kind;     // FP_*
+    int32_t id;
+    int32_t pad[2];
+};
+constexpr int BVH_MIN_PRIMS = 32;    // fewer finite primitives than this: no hierarchy, the loop tests them all
+constexpr int BVH_LEAF_PRIMS = 4;
+
 enum { FP_PLANE = 0, FP_CUBE = 1, FP_CYLINDER = 2, FP_SPHERE = 3, FP_SPHERE_WS = 4, FP_PLANE_GEN = 5 };
 
 struct pt_scene {
@@ -80,6 +101,13 @@ struct pt_scene {
     int32_t* d_chunk_runs; // runs [d_chunk_runs[c], d_chunk_runs[c+1]) lie in chunk c
     int n_chunks;
     FShade* d_fshade;
+    // With a hierarchy (n_bnodes > 0): the primitives outside it (planes) as their own record array and runs.
+    BNode* d_bnodes;
+    int n_bnodes;
+    BPrim* d_bprims;
+    float* d_fdata_top;
+    FRun* d_runs_top;
+    int n_runs_top;
 };
 
 // Camera constants computed on the host in the reference's operation order
@@ -105,6 +133,9 @@ struct RenderArgs {
     const int32_t* chunk_runs;
     int32_t n_chunks;
     const FShade* fshade;
+    const BNode* bnodes;                   // hierarchy over the finite primitives, or n_bnodes = 0
+    const BPrim* bprims;
+    int32_t n_bnodes;
     float* fb;
 };
 

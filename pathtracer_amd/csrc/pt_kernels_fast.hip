@@ -248,12 +248,45 @@ PTD void scan_runs(V3 o, V3 d, float dd, float idd, RP base, KIntP runs, int r0,
 
 PTD Best best_none() { Best b; b.t = __builtin_inff(); b.id = -8; return b; }
 
-// getNearestIntersection (shapes.h:79-100), records by scalar loads.
-PTD Best nearest(V3 o, V3 d, const float* __restrict__ fdata, const FRun* __restrict__ runs, int n_runs) {
-    Best b = best_none();
-    const float dd = dot(d, d);
-    scan_runs(o, d, dd, rcp(dd), as_constant(fdata), as_constant(runs), 0, n_runs, b);
-    return b;
+// The finite primitives through their bounding-volume hierarchy, per lane.  `b` comes in holding the best hit
+// among the primitives outside the hierarchy.  The result is the one the loop over all primitives gives: every
+// primitive whose own test would accept lies in boxes the ray enters no later than the best hit so far, and of two
+// hits at the same distance the lower scene index wins, as the strict '<' of shapes.h:93 has it in scene order.
+PTD void walk_hierarchy(V3 o, V3 d, float dd, float idd, const BNode* __restrict__ nodes, int n_nodes,
+                        const BPrim* __restrict__ prims, Best& b) {
+    const V3 inv = v3(rcp(d.x), rcp(d.y), rcp(d.z));
+    int n = 0;
+    while (n < n_nodes) {
+        const float4 A = reinterpret_cast<const float4*>(nodes)[2 * n];
+        const float4 B = reinterpret_cast<const float4*>(nodes)[2 * n + 1];
+        // slab test; v_min/v_max drop a NaN operand (0 * inf when the origin lies on a slab plane of an axis the
+        // ray does not move along), which then leaves that axis unconstrained on one side: conservative
+        const float ax = (A.x - o.x) * inv.x, bx = (B.x - o.x) * inv.x;
+        const float ay = (A.y - o.y) * inv.y, by = (B.y - o.y) * inv.y;
+        const float az = (A.z - o.z) * inv.z, bz = (B.z - o.z) * inv.z;
+        const float tn = max3(__builtin_fminf(ax, bx), __builtin_fminf(ay, by), __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
+        const float tf = min3(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by), __builtin_fminf(__builtin_fmaxf(az, bz), b.t));
+        const bool hit = tn <= tf;
+        const int skip = __float_as_int(A.w), leaf = __float_as_int(B.w);
+        if (hit && leaf >= 0) {
+            const BPrim* q = prims + (leaf >> 3);
+            for (int k = leaf & 7; k > 0; k--, q++) {
+                Best c;
+                c.t = b.t < __builtin_inff() ? __uint_as_float(__float_as_uint(b.t) + 1u) : b.t;   // accept t <= b.t
+                c.id = -8;
+                const float* R = q->rec;
+                const int id = q->id;
+                switch (q->kind) {
+                    case FP_SPHERE_WS: test_sphere_ws(R, o, d, dd, idd, id, c); break;
+                    case FP_CUBE: test_cube(R, o, d, id, c); break;
+                    case FP_SPHERE: test_sphere(R, o, d, id, c); break;
+                    default: test_cylinder(R, o, d, id, c); break;
+                }
+                if (c.id >= 0 && (c.t < b.t || c.id < b.id)) b = c;
+            }
+        }
+        n = (hit && leaf < 0) ? n + 1 : skip;
+    }
 }
 
 struct Surf {
@@ -399,10 +432,24 @@ PTD bool path_shade(Path& p, const Best& b, const FShade* shade, const DMat* mat
     return p.seg <= n_bounces;
 }
 
+// What the nearest-hit search reads: the record array and runs of the primitives the loop tests, and the
+// hierarchy over the others (n_nodes = 0: none).
+struct SceneRefs {
+    const float* fdata;
+    const FRun* runs;
+    int n_runs;
+    const BNode* nodes;
+    const BPrim* bprims;
+    int n_nodes;
+};
+
 // One iteration of the tracePath loop (bsdf.h:78-166); true = continue.
-PTD bool path_step(Path& p, const float* __restrict__ fdata, const FRun* __restrict__ runs, int n_runs,
-                   const FShade* shade, const DMat* mats, int n_bounces, PhaseClock& clk) {
-    const Best b = nearest(p.o, p.d, fdata, runs, n_runs);
+template <bool BVH>
+PTD bool path_step(Path& p, const SceneRefs& sc, const FShade* shade, const DMat* mats, int n_bounces, PhaseClock& clk) {
+    Best b = best_none();
+    const float dd = dot(p.d, p.d), idd = rcp(dd);
+    scan_runs(p.o, p.d, dd, idd, as_constant(sc.fdata), as_constant(sc.runs), 0, sc.n_runs, b);
+    if (BVH) walk_hierarchy(p.o, p.d, dd, idd, sc.nodes, sc.n_nodes, sc.bprims, b);
     PHASE(clk, 1);
     return path_shade(p, b, shade, mats, n_bounces, clk);
 }
@@ -424,6 +471,7 @@ struct FastCtx {
     PhaseClock clk;
 };
 
+template <bool BVH>
 struct FastTracer {
     using Path = ptf::Path;
     // Lane px prepares pixel px of the tile: jitter-free sample-plane coordinates
@@ -446,7 +494,10 @@ struct FastTracer {
         p.seg = 0;
     }
     static PTD bool step(Path& p, const RenderArgs& a, FastCtx& c) {
-        return path_step(p, a.fdata, a.runs, a.n_runs, c.shade, c.mats, a.n_bounces, c.clk);
+        SceneRefs sc;
+        sc.fdata = a.fdata; sc.runs = a.runs; sc.n_runs = a.n_runs;
+        sc.nodes = a.bnodes; sc.bprims = a.bprims; sc.n_nodes = a.n_bnodes;
+        return path_step<BVH>(p, sc, c.shade, c.mats, a.n_bounces, c.clk);
     }
     static PTD void idle(Path& p) {
         p.o = v3(0.0f, 0.0f, 0.0f); p.d = v3(0.0f, 0.0f, 0.0f);
@@ -476,7 +527,7 @@ struct FastTracer {
     static PTD void phase(FastCtx& c, int i) { PHASE(c.clk, i); (void)c; (void)i; }
 };
 
-template <bool LDS_TABLES>
+template <bool LDS_TABLES, bool BVH>
 __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, uint32_t n_tiles) {
     __shared__ ptw::WaveLds lds[ptw::WAVES_PER_BLOCK];
     __shared__ float pxt[ptw::WAVES_PER_BLOCK][192];
@@ -501,7 +552,7 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, u
     if (tile >= n_tiles) return;
     ctx.pxt = pxt[wave];
     ctx.clk.start();
-    ptw::render_tile<FastTracer>(a, tile, lds[wave], ctx);
+    ptw::render_tile<FastTracer<BVH>>(a, tile, lds[wave], ctx);
     ctx.clk.flush(threadIdx.x & 63);
 }
 
@@ -530,11 +581,12 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_tiled_kernel(RenderArg
     ctx.pxt = pxt[wave];
     ctx.stage = stage;
     ctx.clk.start();
-    ptw::render_tile_blocksync<FastTracer>(a, tile, tile < n_tiles, lds[wave], ctx);
+    ptw::render_tile_blocksync<FastTracer<false>>(a, tile, tile < n_tiles, lds[wave], ctx);
     ctx.clk.flush(threadIdx.x & 63);
 }
 
-__global__ __launch_bounds__(256) void trace_fast_kernel(const float* __restrict__ fdata, const FRun* __restrict__ runs, int n_runs,
+template <bool BVH>
+__global__ __launch_bounds__(256) void trace_fast_kernel(SceneRefs sc,
                                                          const FShade* __restrict__ shade, const DMat* __restrict__ mats,
                                                          const float* __restrict__ o, const float* __restrict__ d,
                                                          const uint32_t* __restrict__ pixel, const uint32_t* __restrict__ sample,
@@ -547,7 +599,7 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(const float* __restrict
     p.d = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     p.coef = v3(1.0f, 1.0f, 1.0f); p.contrib = v3(0.0f, 0.0f, 0.0f); p.seg = 0;
     PhaseClock clk;
-    while (path_step(p, fdata, runs, n_runs, shade, mats, n_bounces, clk)) {}
+    while (path_step<BVH>(p, sc, shade, mats, n_bounces, clk)) {}
     rgb[3 * i] = p.contrib.x; rgb[3 * i + 1] = p.contrib.y; rgb[3 * i + 2] = p.contrib.z;
 }
 
@@ -575,10 +627,15 @@ int ptk_render_fast(const RenderArgs& a, int variant, hipStream_t s) {
             hipLaunchKernelGGL(render_fast_tiled_kernel<true>, dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
         else
             hipLaunchKernelGGL(render_fast_tiled_kernel<false>, dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+    } else if (a.n_bnodes > 0) {
+        if (a.n_mats <= LDS_MAX_MATS && a.n_prims <= LDS_MAX_PRIMS)
+            hipLaunchKernelGGL((render_fast_kernel<true, true>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+        else
+            hipLaunchKernelGGL((render_fast_kernel<false, true>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
     } else if (a.n_prims <= LDS_MAX_PRIMS && a.n_mats <= LDS_MAX_MATS)
-        hipLaunchKernelGGL(render_fast_kernel<true>, dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+        hipLaunchKernelGGL((render_fast_kernel<true, false>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
     else
-        hipLaunchKernelGGL(render_fast_kernel<false>, dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+        hipLaunchKernelGGL((render_fast_kernel<false, false>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
     PT_CHECK(hipGetLastError());
     return 0;
 }
@@ -586,8 +643,18 @@ int ptk_render_fast(const RenderArgs& a, int variant, hipStream_t s) {
 int ptk_trace_paths_fast(const pt_scene* sc, const float* o, const float* d, const uint32_t* pixel,
                          const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, float* rgb, hipStream_t s) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(trace_fast_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sc->d_fdata, sc->d_runs, sc->n_runs,
-                       sc->d_fshade, sc->d_mats, o, d, pixel, sample, n, seed_hash, n_bounces, rgb);
+    SceneRefs refs;
+    if (sc->n_bnodes > 0) {
+        refs.fdata = sc->d_fdata_top; refs.runs = sc->d_runs_top; refs.n_runs = sc->n_runs_top;
+        refs.nodes = sc->d_bnodes; refs.bprims = sc->d_bprims; refs.n_nodes = sc->n_bnodes;
+        hipLaunchKernelGGL(trace_fast_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, s, refs,
+                           sc->d_fshade, sc->d_mats, o, d, pixel, sample, n, seed_hash, n_bounces, rgb);
+    } else {
+        refs.fdata = sc->d_fdata; refs.runs = sc->d_runs; refs.n_runs = sc->n_runs;
+        refs.nodes = nullptr; refs.bprims = nullptr; refs.n_nodes = 0;
+        hipLaunchKernelGGL(trace_fast_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, s, refs,
+                           sc->d_fshade, sc->d_mats, o, d, pixel, sample, n, seed_hash, n_bounces, rgb);
+    }
     PT_CHECK(hipGetLastError());
     return 0;
 }

@@ -89,3 +89,67 @@ def test_lds_tiled_loop_equals_scalar_loop_bitwise():
     a = sc.render(pt.make_config(70, 3, 4, math_mode=pt.PT_MATH_FAST_SCALAR))
     b = sc.render(pt.make_config(70, 3, 4, math_mode=pt.PT_MATH_FAST_LDS))
     assert torch.equal(a, b)
+
+
+def _mixed_scene_text(n, walls=True, seed=3):
+    """Cylinders, ellipsoids, spheres and cubes with random poses; every fifth shape is an exact duplicate of
+    the one before it (equal hit distances: the lower index has to win)."""
+    rng = np.random.default_rng(seed)
+    lines = ["material base albedo 0.4 0.4 0.4", "material red albedo 1 0 0", "material light emissive 20 18 14",
+             "material glass f0 0.02 specularColor 0.8 0.8 0.8 IOR 1.5 transparency 1 bsdfType 1 refractionColor 0.9 0 0",
+             "material mirror f0 0.9 specularColor 0.9 0.9 0.9 specularRoughness 0.2"]
+    if walls:
+        lines += ["plane base bounds -15 -15 15 15 rotate pi/2 1 0 0 translate 0 -1 0",
+                  "plane red bounds -15 -15 15 15 translate 0 0 -5",
+                  "plane light bounds -0.5 -0.5 0.5 0.5 rotate -pi/2 1 0 0 translate 0 0.97 -3.25"]
+    else:
+        lines += ["cube light translate 0 3 -3 scale 4 0.1 4"]
+    prev = None
+    for k in range(n):
+        if k % 5 == 4 and prev:
+            lines.append(prev)
+            continue
+        kind = ("cylinder", "sphere", "sphere", "cube")[k % 4]
+        mat = ("base", "red", "glass", "mirror")[int(rng.integers(4))]
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        pos = rng.uniform([-0.9, -0.9, -4.8], [0.9, 0.9, -1.6])
+        s = rng.uniform(0.05, 0.25, size=3)
+        scale = "scale %.4f" % s[0] if (kind == "sphere" and k % 8 < 4) else "scale %.4f %.4f %.4f" % tuple(s)
+        prev = "%s %s rotate %.4f %.4f %.4f %.4f translate %.4f %.4f %.4f %s" % (
+            kind, mat, rng.uniform(0, 3.1), ax[0], ax[1], ax[2], pos[0], pos[1], pos[2], scale)
+        lines.append(prev)
+    return "\n".join(lines) + "\n"
+
+
+def test_hierarchy_equals_loop_over_all_primitives_bitwise():
+    """PT_MATH_FAST searches scenes with many finite primitives through a bounding-volume hierarchy; the nearest
+    hit, and so the image, is the one the loop over all primitives (PT_MATH_FAST_SCALAR) finds, bit for bit."""
+    import torch
+    import pathtracer_amd as pt
+    small = pt.Scene(*pt.default_scene())
+    assert small.bvh_nodes == 0                        # 4 finite primitives: no hierarchy
+    cases = ((pt.synthetic_scene(5000, 4989, 12345), (160, 90, 4, 5)), (pt.synthetic_scene(700, 300, 7), (130, 50, 3, 5)),
+             (pt.glass_grid_scene(6), (200, 120, 4, 31)),
+             (pt.parse_scene(_mixed_scene_text(120)), (192, 108, 8, 8)),
+             (pt.parse_scene(_mixed_scene_text(40, walls=False)), (96, 64, 8, 5)))
+    for scene, (w, h, spp, depth) in cases:
+        sc = pt.Scene(*scene)
+        assert sc.bvh_nodes > 0
+        a = sc.render(pt.make_config(w, h, spp, n_bounces=depth, math_mode=pt.PT_MATH_FAST))
+        b = sc.render(pt.make_config(w, h, spp, n_bounces=depth, math_mode=pt.PT_MATH_FAST_SCALAR))
+        assert torch.isfinite(a).all() and float(a.sum()) > 0.0
+        assert torch.equal(a, b)
+    # explicit rays through tracePath: the hierarchy there too, against the parity-order kernel's loop
+    prims, n, mats, nm = pt.parse_scene(_mixed_scene_text(120))
+    sc = pt.Scene(prims, n, mats, nm)
+    rng = np.random.default_rng(11)
+    nr = 4096
+    o = np.zeros((nr, 3), np.float32)
+    d = rng.normal(size=(nr, 3)); d[:, 2] = -np.abs(d[:, 2]) - 1.0
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    px = np.arange(nr, dtype=np.uint32); smp = np.zeros(nr, np.uint32)
+    args = [torch.from_numpy(x).cuda() for x in (o, d, px, smp)]
+    fast = sc.trace_paths(*args, seed=0, n_bounces=0, math_mode=pt.PT_MATH_FAST).cpu().numpy()
+    par = sc.trace_paths(*args, seed=0, n_bounces=0, math_mode=pt.PT_MATH_PARITY).cpu().numpy()
+    # one segment: the radiance is the emission of whatever the ray hits first
+    assert (np.abs(fast - par).max(axis=1) > 1e-3).mean() < 0.002
