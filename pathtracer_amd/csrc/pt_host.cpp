@@ -265,7 +265,7 @@ int pack_runs(const std::vector<Baked>& baked, const std::vector<int>& ids, std:
 // Median-split hierarchy over ids[lo, hi), appended to `nodes` in depth-first order.  Boxes are padded so that
 // the rounding of the kernels' slab test can never cull a primitive its own test would accept.
 void build_bvh(const std::vector<Baked>& baked, std::vector<int>& ids, int lo, int hi, std::vector<BNode>& nodes,
-               std::vector<BPrim>& bprims) {
+               std::vector<BPrim>& bprims, int leaf_prims) {
     const size_t me = nodes.size();
     nodes.push_back(BNode());
     float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -282,8 +282,8 @@ void build_bvh(const std::vector<Baked>& baked, std::vector<int>& ids, int lo, i
         const float pad = 1e-4f * (1.0f + fmaxf(fabsf(blo[a]), fabsf(bhi[a])));
         nodes[me].lo[a] = blo[a] - pad; nodes[me].hi[a] = bhi[a] + pad;
     }
-    if (hi - lo <= BVH_LEAF_PRIMS) {
-        nodes[me].leaf = (int32_t)((bprims.size() << 3) | (size_t)(hi - lo));
+    if (hi - lo <= leaf_prims) {
+        nodes[me].leaf = (int32_t)((bprims.size() << 4) | (size_t)(hi - lo));
         std::sort(ids.begin() + lo, ids.begin() + hi);
         for (int i = lo; i < hi; i++) {
             const Baked& b = baked[ids[i]];
@@ -302,8 +302,8 @@ void build_bvh(const std::vector<Baked>& baked, std::vector<int>& ids, int lo, i
             return cx < cy || (cx == cy && x < y);
         });
         nodes[me].leaf = -1;
-        build_bvh(baked, ids, lo, mid, nodes, bprims);
-        build_bvh(baked, ids, mid, hi, nodes, bprims);
+        build_bvh(baked, ids, lo, mid, nodes, bprims, leaf_prims);
+        build_bvh(baked, ids, mid, hi, nodes, bprims, leaf_prims);
     }
     nodes[me].skip = (int32_t)nodes.size();
 }
@@ -416,7 +416,9 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
     std::vector<BNode> bnodes;
     std::vector<BPrim> bprims;
     if ((int)finite.size() >= BVH_MIN_PRIMS) {
-        build_bvh(baked, finite, 0, (int)finite.size(), bnodes, bprims);
+        int leaf_prims = BVH_LEAF_PRIMS;
+        if (const char* e = std::getenv("PT_BVH_LEAF")) { const int v = std::atoi(e); if (v >= 1 && v <= 15) leaf_prims = v; }
+        build_bvh(baked, finite, 0, (int)finite.size(), bnodes, bprims, leaf_prims);
         if (top.empty()) {   // the loop over the other primitives still wants one (empty) chunk to read
             fdata_top.assign(FDATA_CHUNK + 16, 0.0f);
         } else {

@@ -256,36 +256,41 @@ PTD void walk_hierarchy(V3 o, V3 d, float dd, float idd, const BNode* __restrict
                         const BPrim* __restrict__ prims, Best& b) {
     const V3 inv = v3(rcp(d.x), rcp(d.y), rcp(d.z));
     int n = 0;
-    while (n < n_nodes) {
-        const float4 A = reinterpret_cast<const float4*>(nodes)[2 * n];
-        const float4 B = reinterpret_cast<const float4*>(nodes)[2 * n + 1];
-        // slab test; v_min/v_max drop a NaN operand (0 * inf when the origin lies on a slab plane of an axis the
-        // ray does not move along), which then leaves that axis unconstrained on one side: conservative
-        const float ax = (A.x - o.x) * inv.x, bx = (B.x - o.x) * inv.x;
-        const float ay = (A.y - o.y) * inv.y, by = (B.y - o.y) * inv.y;
-        const float az = (A.z - o.z) * inv.z, bz = (B.z - o.z) * inv.z;
-        const float tn = max3(__builtin_fminf(ax, bx), __builtin_fminf(ay, by), __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
-        const float tf = min3(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by), __builtin_fminf(__builtin_fmaxf(az, bz), b.t));
-        const bool hit = tn <= tf;
-        const int skip = __float_as_int(A.w), leaf = __float_as_int(B.w);
-        if (hit && leaf >= 0) {
-            const BPrim* q = prims + (leaf >> 3);
-            for (int k = leaf & 7; k > 0; k--, q++) {
-                Best c;
-                c.t = b.t < __builtin_inff() ? __uint_as_float(__float_as_uint(b.t) + 1u) : b.t;   // accept t <= b.t
-                c.id = -8;
-                const float* R = q->rec;
-                const int id = q->id;
-                switch (q->kind) {
-                    case FP_SPHERE_WS: test_sphere_ws(R, o, d, dd, idd, id, c); break;
-                    case FP_CUBE: test_cube(R, o, d, id, c); break;
-                    case FP_SPHERE: test_sphere(R, o, d, id, c); break;
-                    default: test_cylinder(R, o, d, id, c); break;
-                }
-                if (c.id >= 0 && (c.t < b.t || c.id < b.id)) b = c;
-            }
+    for (;;) {
+        // Walk until this lane stands on a leaf its ray enters (or has no node left).  The lanes of a wave leave this
+        // loop together, so the primitive tests below run with most lanes on, not for one lane at a time.
+        int leaf = -1;
+        while (n < n_nodes) {
+            const float4 A = reinterpret_cast<const float4*>(nodes)[2 * n];
+            const float4 B = reinterpret_cast<const float4*>(nodes)[2 * n + 1];
+            // slab test; v_min/v_max drop a NaN operand (0 * inf when the origin lies on a slab plane of an axis
+            // the ray does not move along), which leaves that axis unconstrained on one side: conservative
+            const float ax = (A.x - o.x) * inv.x, bx = (B.x - o.x) * inv.x;
+            const float ay = (A.y - o.y) * inv.y, by = (B.y - o.y) * inv.y;
+            const float az = (A.z - o.z) * inv.z, bz = (B.z - o.z) * inv.z;
+            const float tn = max3(__builtin_fminf(ax, bx), __builtin_fminf(ay, by), __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
+            const float tf = min3(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by), __builtin_fminf(__builtin_fmaxf(az, bz), b.t));
+            const bool hit = tn <= tf;
+            const int skip = __float_as_int(A.w), lf = __float_as_int(B.w);
+            n = (hit && lf < 0) ? n + 1 : skip;
+            if (hit && lf >= 0) { leaf = lf; break; }
         }
-        n = (hit && leaf < 0) ? n + 1 : skip;
+        if (leaf < 0) break;
+        const BPrim* q = prims + (leaf >> 4);
+        for (int k = leaf & 15; k > 0; k--, q++) {
+            Best c;
+            c.t = b.t < __builtin_inff() ? __uint_as_float(__float_as_uint(b.t) + 1u) : b.t;   // accept t <= b.t
+            c.id = -8;
+            const float* R = q->rec;
+            const int id = q->id;
+            switch (q->kind) {
+                case FP_SPHERE_WS: test_sphere_ws(R, o, d, dd, idd, id, c); break;
+                case FP_CUBE: test_cube(R, o, d, id, c); break;
+                case FP_SPHERE: test_sphere(R, o, d, id, c); break;
+                default: test_cylinder(R, o, d, id, c); break;
+            }
+            if (c.id >= 0 && (c.t < b.t || c.id < b.id)) b = c;
+        }
     }
 }
 
