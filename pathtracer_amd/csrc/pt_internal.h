@@ -136,6 +136,8 @@ struct RenderArgs {
     const BNode* bnodes;                   // hierarchy over the finite primitives, or n_bnodes = 0
     const BPrim* bprims;
     int32_t n_bnodes;
+    int32_t walk_budget;                   // hierarchy nodes a lane visits per loop iteration
+    int32_t shade_gate;                    // lanes whose search is over before they are shaded together
     float* fb;
 };
 

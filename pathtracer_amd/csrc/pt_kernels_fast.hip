@@ -17,6 +17,8 @@
 #include "pt_internal.h"
 #include "pt_wavepool.h"
 
+#include <type_traits>
+
 #define PTD __device__ __forceinline__
 
 // Development aid (make prof): per-phase shader-cycle shares of the render loop, stamped with s_memtime.
@@ -252,15 +254,17 @@ PTD Best best_none() { Best b; b.t = __builtin_inff(); b.id = -8; return b; }
 // among the primitives outside the hierarchy.  The result is the one the loop over all primitives gives: every
 // primitive whose own test would accept lies in boxes the ray enters no later than the best hit so far, and of two
 // hits at the same distance the lower scene index wins, as the strict '<' of shapes.h:93 has it in scene order.
+// The walk is resumable: it starts at node `n` (0 = the root), visits at most `budget` nodes and leaves the node
+// to go on from in `n` (n >= n_nodes: finished).
 PTD void walk_hierarchy(V3 o, V3 d, float dd, float idd, const BNode* __restrict__ nodes, int n_nodes,
-                        const BPrim* __restrict__ prims, Best& b) {
+                        const BPrim* __restrict__ prims, Best& b, int& n, int budget) {
     const V3 inv = v3(rcp(d.x), rcp(d.y), rcp(d.z));
-    int n = 0;
     for (;;) {
         // Walk until this lane stands on a leaf its ray enters (or has no node left).  The lanes of a wave leave this
         // loop together, so the primitive tests below run with most lanes on, not for one lane at a time.
         int leaf = -1;
-        while (n < n_nodes) {
+        while (n < n_nodes && budget > 0) {
+            budget--;
             const float4 A = reinterpret_cast<const float4*>(nodes)[2 * n];
             const float4 B = reinterpret_cast<const float4*>(nodes)[2 * n + 1];
             // slab test; v_min/v_max drop a NaN operand (0 * inf when the origin lies on a slab plane of an axis
@@ -454,9 +458,38 @@ PTD bool path_step(Path& p, const SceneRefs& sc, const FShade* shade, const DMat
     Best b = best_none();
     const float dd = dot(p.d, p.d), idd = rcp(dd);
     scan_runs(p.o, p.d, dd, idd, as_constant(sc.fdata), as_constant(sc.runs), 0, sc.n_runs, b);
-    if (BVH) walk_hierarchy(p.o, p.d, dd, idd, sc.nodes, sc.n_nodes, sc.bprims, b);
+    if (BVH) { int n = 0; walk_hierarchy(p.o, p.d, dd, idd, sc.nodes, sc.n_nodes, sc.bprims, b, n, 0x7fffffff); }
     PHASE(clk, 1);
     return path_shade(p, b, shade, mats, n_bounces, clk);
+}
+
+// A path of the render kernel that searches a hierarchy: the segment's nearest-hit search is spread over several
+// iterations of the wave's loop, so its state travels with the path.
+struct WalkPath : Path {
+    int node;      // -1: the segment's search has not begun; otherwise the hierarchy node to go on from
+    Best best;
+};
+
+// One iteration of the wave's loop for such a path.  A segment costs a ray anything from a handful to hundreds
+// of node visits; were every iteration a whole segment, the wave would wait for its slowest ray each time.
+// Instead every lane visits at most walk_budget nodes per iteration, and lanes whose search is over are shaded
+// (and start their next segment) once shade_gate of them have gathered or nobody is searching any more, so that
+// the shading code does not run for one or two lanes at a time.
+PTD bool path_step_walk(WalkPath& p, const SceneRefs& sc, const FShade* shade, const DMat* mats, int n_bounces,
+                        int walk_budget, int shade_gate, PhaseClock& clk) {
+    const float dd = dot(p.d, p.d), idd = rcp(dd);
+    if (p.node < 0) {
+        p.best = best_none();
+        scan_runs(p.o, p.d, dd, idd, as_constant(sc.fdata), as_constant(sc.runs), 0, sc.n_runs, p.best);
+        p.node = 0;
+    }
+    walk_hierarchy(p.o, p.d, dd, idd, sc.nodes, sc.n_nodes, sc.bprims, p.best, p.node, walk_budget);
+    PHASE(clk, 1);
+    const bool done = p.node >= sc.n_nodes;
+    const unsigned long long done_m = __ballot(done), busy_m = __ballot(!done);
+    if (!done || (__popcll(done_m) < shade_gate && busy_m != 0ull)) return true;
+    p.node = -1;
+    return path_shade(p, p.best, shade, mats, n_bounces, clk);
 }
 
 }  // namespace ptf
@@ -478,7 +511,7 @@ struct FastCtx {
 
 template <bool BVH>
 struct FastTracer {
-    using Path = ptf::Path;
+    using Path = typename std::conditional<BVH, ptf::WalkPath, ptf::Path>::type;
     // Lane px prepares pixel px of the tile: jitter-free sample-plane coordinates
     // (main.cu:62) and the pixel's RNG key.
     static PTD void prologue(const RenderArgs& a, FastCtx& c, uint32_t px, const ptw::PixelRef& ref) {
@@ -497,12 +530,21 @@ struct FastTracer {
         p.coef = v3(1.0f, 1.0f, 1.0f);
         p.contrib = v3(0.0f, 0.0f, 0.0f);
         p.seg = 0;
+        begin_search(p);
     }
+    static PTD void begin_search(ptf::Path&) {}
+    static PTD void begin_search(ptf::WalkPath& p) { p.node = -1; }
     static PTD bool step(Path& p, const RenderArgs& a, FastCtx& c) {
         SceneRefs sc;
         sc.fdata = a.fdata; sc.runs = a.runs; sc.n_runs = a.n_runs;
         sc.nodes = a.bnodes; sc.bprims = a.bprims; sc.n_nodes = a.n_bnodes;
-        return path_step<BVH>(p, sc, c.shade, c.mats, a.n_bounces, c.clk);
+        return step_path(p, sc, a, c);
+    }
+    static PTD bool step_path(ptf::Path& p, const SceneRefs& sc, const RenderArgs& a, FastCtx& c) {
+        return path_step<false>(p, sc, c.shade, c.mats, a.n_bounces, c.clk);
+    }
+    static PTD bool step_path(ptf::WalkPath& p, const SceneRefs& sc, const RenderArgs& a, FastCtx& c) {
+        return path_step_walk(p, sc, c.shade, c.mats, a.n_bounces, a.walk_budget, a.shade_gate, c.clk);
     }
     static PTD void idle(Path& p) {
         p.o = v3(0.0f, 0.0f, 0.0f); p.d = v3(0.0f, 0.0f, 0.0f);
