@@ -636,6 +636,116 @@ inline vec3 tracePath(Shape* const* scene, int n_objects, ray& r, pt_rng* s, int
 }
 
 // ----------------------------------------------------------------------------
+// bsdf_alternative.h — the class-based BSDF interface (Lambertian /
+// SmoothDielectric selected by Material::bsdfType) and its tracePath.  The
+// reference does not include this file from main.cu; it is restated here as the
+// second shading model.  RNG slots of segment s: 2+6s+{0 dielectric choice,
+// 1,2 Lambertian u1,u2, 5 Russian roulette}.  Defined values for what the text
+// leaves undefined: the `default:` case of the switch (bsdf_alternative.h:195-199
+// fills shadowing locals, the outer ones stay uninitialised) is Lambertian; a
+// SmoothDielectric with f0 == 0 and transparency == 0 (`*transmission` never
+// written, :131-132) counts as transmission = false.
+// ----------------------------------------------------------------------------
+struct ONB { vec3 x, y, z; };
+
+inline ONB constructONB(vec3 N) {                       // bsdf_alternative.h:9-18
+    float sign = (N.z() < 0 ? -1.0f : 1.0f);
+    float a = -1 / (sign + N.z());
+    float b = N.x() * N.y() * a;
+    ONB res;
+    res.x = vec3(1 + sign * (N.x() * N.x()) * a, sign * b, -sign * N.x());
+    res.y = vec3(b, sign + (N.y() * N.y()) * a, -N.y());
+    res.z = N;
+    return res;
+}
+inline vec3 inverseONB(const ONB& onb, vec3 v) {        // bsdf_alternative.h:24-26
+    return v.x() * onb.x + v.y() * onb.y + v.z() * onb.z;
+}
+
+struct Lambertian {                                     // bsdf_alternative.h:74-114
+    static vec3 evalBSDF(const ray& r, vec3 sampleDirection, const IntersectionPoint& p, const Material& m) {
+        vec3 N = p.normal;
+        vec3 V = -1.0f * r.direction();
+        vec3 L = sampleDirection;
+        float NDotL = N.dot(L);
+        float NDotV = N.dot(V);
+        if (NDotL <= 0.0f || NDotV <= 0.0f) return vec3(0.0f, 0.0f, 0.0f);
+        vec3 out = (float)(1.0f / PI) * m.albedo;
+        return out * fmaxf(fminf(NDotL, 1.0f), 0.0f);
+    }
+    static vec3 sampleBSDF(const ray&, const IntersectionPoint& p, const Material&, float u1, float u2) {
+        ONB onb = constructONB(p.normal);
+        vec3 res = sampleHemisphere(u1, u2);
+        return inverseONB(onb, res);
+    }
+    static float EvalPDF(const ray&, vec3 sampleDirection, const IntersectionPoint& p, const Material&) {
+        return (float)((double)fabsf(sampleDirection.dot(p.normal)) * (1.0f / PI));
+    }
+};
+
+struct SmoothDielectric {                               // bsdf_alternative.h:116-149
+    static vec3 evalBSDF(const Material& m) { return m.specularColor; }
+    // `u` is drawn by the caller only when it is needed (:133), `need_u` says so.
+    static void probabilities(const ray& r, const IntersectionPoint& p, const Material& m, float* p_reflect, float* p_refract) {
+        float pr = getFresnelRatio(p.normal, r.direction(), m.f0, 1.0f, p.inside ? m.IOR : 1.0f, !p.inside ? 1.0f : m.IOR);
+        float pt = 1 - pr;
+        pr *= (m.f0 > 0);
+        pt *= (m.transparency > 0);
+        *p_reflect = pr; *p_refract = pt;
+    }
+    static vec3 sampleBSDF(const ray& r, const IntersectionPoint& p, float p_reflect, float p_refract, float u, bool* transmission) {
+        if (p_reflect == 0.0f && p_refract == 0.0f) { *transmission = false; return vec3(0.0f, 0.0f, 0.0f); }
+        if (u < p_reflect / (p_reflect + p_refract)) {
+            *transmission = false;
+            return reflect(r.direction(), p.normal).normalized();
+        }
+        *transmission = true;
+        return refract(r.direction(), p.normal, (p.inside ? p.material.IOR : 1.0f / p.material.IOR)).normalized();
+    }
+    static float EvalPDF(bool transmission, float p_transmission) { return transmission ? p_transmission : 1 - p_transmission; }
+};
+
+// bsdf_alternative.h:153-219
+inline vec3 tracePathAlternative(Shape* const* scene, int n_objects, ray& r, pt_rng* s, int n_bounces = 5) {
+    vec3 contribution(0.0f, 0.0f, 0.0f);
+    vec3 coefficient = vec3(1.0f, 1.0f, 1.0f);
+    const uint32_t key = s->key;
+    for (int i = 0; i <= n_bounces; i++) {
+        const uint32_t slot = 2u + 6u * (uint32_t)i;
+        IntersectionPoint min_p = getNearestIntersection(r, scene, n_objects);
+        if (!min_p.intersects) break;
+        Material material = min_p.material;
+        if (material.emissive.norm() > 0) contribution = contribution + material.emissive.cwiseProduct(coefficient);
+        vec3 newPosition = min_p.position;
+        vec3 newDirection, f;
+        float pdf;
+        if (material.bsdfType == 1) {
+            float p_reflect, p_refract;
+            SmoothDielectric::probabilities(r, min_p, material, &p_reflect, &p_refract);
+            bool transmission;
+            float u = (p_reflect == 0.0f && p_refract == 0.0f) ? 0.0f : rng_to_uniform(rng_bits(key, slot));
+            newDirection = SmoothDielectric::sampleBSDF(r, min_p, p_reflect, p_refract, u, &transmission).normalized();
+            f = SmoothDielectric::evalBSDF(material);
+            pdf = SmoothDielectric::EvalPDF(transmission, p_refract);
+        } else {
+            float u1 = rng_to_uniform(rng_bits(key, slot + 1u));
+            float u2 = rng_to_uniform(rng_bits(key, slot + 2u));
+            newDirection = Lambertian::sampleBSDF(r, min_p, material, u1, u2).normalized();
+            f = Lambertian::evalBSDF(r, newDirection, min_p, material);
+            pdf = Lambertian::EvalPDF(r, newDirection, min_p, material);
+        }
+        if (pdf > 0.0f) coefficient = coefficient.cwiseProduct(f / pdf);
+        else break;
+        float p = fmaxf(coefficient.x(), fmaxf(coefficient.y(), coefficient.z()));
+        float u = rng_to_uniform(rng_bits(key, slot + 5u));
+        if (p < u) break;
+        coefficient = coefficient * (1 / p);
+        r = ray(newPosition, newDirection);
+    }
+    return contribution;
+}
+
+// ----------------------------------------------------------------------------
 // main.cu:22-28 config_t plus the literals the reference hard-codes
 // (n_samples main.cu:54, n_bounces bsdf.h:75) and a row range for tiling.
 // ----------------------------------------------------------------------------
@@ -655,7 +765,7 @@ inline float host_focal_length(int nx, int ny, float v_height, float fov_deg) {
 
 // main.cu:30-69 — one pixel of `render` (row j = 0 is the bottom of the image).
 inline vec3 renderPixel(const config_t& config, Shape* const* scene, int n_objects, int i, int j,
-                        int n_samples, int n_bounces, uint32_t seed) {
+                        int n_samples, int n_bounces, uint32_t seed, int bsdf_model = 0) {
     int max_x = config.max_x, max_y = config.max_y;
     int pixel_index = j * max_x + i;
     vec3 camera_pos = config.camera_pos;
@@ -676,7 +786,8 @@ inline vec3 renderPixel(const config_t& config, Shape* const* scene, int n_objec
         vec3 p_center = pixel00_loc + (pixel_delta_u * (i - 0.5f + jx)) + (pixel_delta_v * (max_y - j - 0.5f + jy));
         vec3 direction = (p_center - camera_pos).normalized();
         ray r = ray(camera_pos, direction);
-        totalLight = totalLight + tracePath(scene, n_objects, r, &s, n_bounces);
+        totalLight = totalLight + (bsdf_model == 1 ? tracePathAlternative(scene, n_objects, r, &s, n_bounces)
+                                                   : tracePath(scene, n_objects, r, &s, n_bounces));
     }
     return totalLight / ((float)n_samples);
 }
