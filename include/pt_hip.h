@@ -57,6 +57,12 @@ enum {
     PT_MATH_FAST_SCALAR = 2, /* primitive records fetched by scalar loads */
     PT_MATH_FAST_LDS = 3     /* primitive records staged chunk by chunk in LDS by the workgroup */
 };
+/* Shading model: which tracePath the kernels run. */
+enum {
+    PT_BSDF_REFERENCE = 0, /* tracePath of bsdf.h:73-168 — what main.cu compiles */
+    PT_BSDF_CLASSES = 1    /* tracePath of bsdf_alternative.h:153-219: Lambertian / SmoothDielectric classes chosen by
+                            * Material::bsdfType (materials.h:38); that file is not compiled by the reference */
+};
 /* Framebuffer layout of pt_render. */
 enum {
     PT_FB_AOS = 0, /* fb[(j*max_x+i)*3 + c]  — the reference's vec3* fb (main.cu:68) */
@@ -86,6 +92,7 @@ typedef struct pt_config {
     int32_t math_mode;
     int32_t row_step;
     int32_t fb_compact;
+    int32_t bsdf_model;
 } pt_config;
 
 typedef struct pt_scene pt_scene; /* opaque; owns the device copy of the primitive table */
@@ -146,6 +153,11 @@ int pt_nearest_batch(const pt_scene* scene, const float* d_o, const float* d_d, 
 int pt_trace_paths(const pt_scene* scene, const float* d_o, const float* d_d, const uint32_t* d_pixel,
                    const uint32_t* d_sample, int n_rays, uint32_t seed, int n_bounces, int math_mode,
                    float* d_rgb, void* stream);
+
+/* The same for the tracePath of bsdf_alternative.h:153-219 (PT_BSDF_CLASSES). */
+int pt_trace_paths_alt(const pt_scene* scene, const float* d_o, const float* d_d, const uint32_t* d_pixel,
+                       const uint32_t* d_sample, int n_rays, uint32_t seed, int n_bounces, int math_mode,
+                       float* d_rgb, void* stream);
 
 /* Raw draws of the counter RNG: bits and (0,1] uniforms of slots [0,n_slots) of
  * stream (seed, pixel, sample), computed on the device. */

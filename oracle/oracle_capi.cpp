@@ -46,6 +46,7 @@ struct oracle_config {
     int n_bounces;                          // bsdf.h:75
     unsigned seed;
     int row_begin, row_end;                 // rows [row_begin,row_end) are rendered
+    int bsdf_model;                         // 0 = tracePath of bsdf.h, 1 = tracePath of bsdf_alternative.h
 };
 struct oracle_stats {
     uint64_t samples, segments, hits, tests[4], sphere_roots, cyl_roots, emissive, beer, fresnel, fresnel_dense, mode[4];
@@ -257,6 +258,19 @@ void oracle_trace_paths(void* scene, const float* o, const float* d, const unsig
     }
 }
 
+// The same for the tracePath of bsdf_alternative.h:153-219.
+void oracle_trace_paths_alt(void* scene, const float* o, const float* d, const unsigned* pixel, const unsigned* sample,
+                            int n_rays, unsigned seed, int n_bounces, float* rgb) {
+    Scene* sc = static_cast<Scene*>(scene);
+    for (int i = 0; i < n_rays; i++) {
+        ray r(vec3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), vec3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
+        pt_rng s = rng_init(seed, pixel[i], sample[i]);
+        s.slot = 2;
+        vec3 c = tracePathAlternative(sc->ptrs.data(), (int)sc->ptrs.size(), r, &s, n_bounces);
+        for (int k = 0; k < 3; k++) rgb[3 * i + k] = c[k];
+    }
+}
+
 // Raw RNG access: bits and uniforms of draw slots [0, n_slots) of one stream.
 void oracle_rng(unsigned seed, unsigned pixel, unsigned sample, int n_slots, unsigned* bits, float* uniforms) {
     pt_rng s = rng_init(seed, pixel, sample);
@@ -328,7 +342,7 @@ int oracle_render_rows(void* scene, const oracle_config* cfg, const int* rows, i
             if (rows) j = rows[j];
             for (int i = 0; i < config.max_x; i++) {
                 vec3 c = renderPixel(config, sc->ptrs.data(), (int)sc->ptrs.size(), i, j,
-                                     cfg->n_samples, cfg->n_bounces, cfg->seed);
+                                     cfg->n_samples, cfg->n_bounces, cfg->seed, cfg->bsdf_model);
                 float* px = fb + ((size_t)j * config.max_x + i) * 3;
                 px[0] = c[0]; px[1] = c[1]; px[2] = c[2];
             }

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libpt_hip.so")
 PT_PLANE, PT_CUBE, PT_CYLINDER, PT_SPHERE = 0, 1, 2, 3
 PT_MATH_PARITY, PT_MATH_FAST, PT_MATH_FAST_SCALAR, PT_MATH_FAST_LDS = 0, 1, 2, 3
 PT_FB_AOS, PT_FB_SOA = 0, 1
+PT_BSDF_REFERENCE, PT_BSDF_CLASSES = 0, 1
 
 
 class pt_material(C.Structure):
@@ -38,7 +39,7 @@ class pt_config(C.Structure):
         ("focal_length", C.c_float), ("view_port_height", C.c_float),
         ("n_samples", C.c_int32), ("n_bounces", C.c_int32), ("seed", C.c_uint32),
         ("row_begin", C.c_int32), ("row_end", C.c_int32), ("fb_layout", C.c_int32), ("math_mode", C.c_int32),
-        ("row_step", C.c_int32), ("fb_compact", C.c_int32),
+        ("row_step", C.c_int32), ("fb_compact", C.c_int32), ("bsdf_model", C.c_int32),
     ]
 
 
@@ -68,6 +69,7 @@ def _load():
     L.pt_raypath_batch.argtypes = [vp, i32, vp, vp, i32, i32] + [vp] * 9 + [vp]
     L.pt_nearest_batch.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.pt_trace_paths.argtypes = [vp, vp, vp, vp, vp, i32, u32, i32, i32, vp, vp]
+    L.pt_trace_paths_alt.argtypes = [vp, vp, vp, vp, vp, i32, u32, i32, i32, vp, vp]
     L.pt_rng_draws.argtypes = [i32, u32, u32, u32, i32, vp, vp, vp]
     L.pt_ppm_p3.restype = C.c_long
     L.pt_ppm_p3.argtypes = [vp, i32, i32, C.c_char_p, C.c_long]
@@ -84,7 +86,7 @@ lib = _load()
 EXPORTS = [
     "pt_scene_upload", "pt_scene_free", "pt_scene_device", "pt_scene_bvh_nodes", "pt_default_scene", "pt_glass_grid_scene",
     "pt_synthetic_scene", "pt_focal_length", "pt_render", "pt_raypath_batch", "pt_nearest_batch",
-    "pt_trace_paths", "pt_rng_draws", "pt_ppm_p3", "pt_last_error", "pt_version",
+    "pt_trace_paths", "pt_trace_paths_alt", "pt_rng_draws", "pt_ppm_p3", "pt_last_error", "pt_version",
     "pt_scene_parse", "pt_ppm_p6", "pt_pfm",
 ]
 
@@ -125,7 +127,7 @@ def synthetic_scene(n_spheres, n_cubes, seed=12345):
 
 
 def make_config(width, height, spp, n_bounces=5, seed=0, row_begin=0, row_end=None, camera=(0.0, 0.0, 0.0),
-                fb_layout=PT_FB_AOS, math_mode=PT_MATH_FAST, row_step=1, fb_compact=0):
+                fb_layout=PT_FB_AOS, math_mode=PT_MATH_FAST, row_step=1, fb_compact=0, bsdf_model=PT_BSDF_REFERENCE):
     """config_t of main.cu:234 with the reference's camera (origin, v_height 5, fov 45)."""
     cfg = pt_config()
     cfg.camera_pos[:] = camera
@@ -137,6 +139,7 @@ def make_config(width, height, spp, n_bounces=5, seed=0, row_begin=0, row_end=No
     cfg.row_end = height if row_end is None else row_end
     cfg.fb_layout, cfg.math_mode = fb_layout, math_mode
     cfg.row_step, cfg.fb_compact = row_step, fb_compact
+    cfg.bsdf_model = bsdf_model
     return cfg
 
 
@@ -273,13 +276,13 @@ class Scene:
                                         _ptr(res["pos"]), _ptr(res["nrm"]), _ptr(res["inside"]), _stream()))
         return res
 
-    def trace_paths(self, o, d, pixel, sample, seed=0, n_bounces=5, math_mode=PT_MATH_PARITY):
+    def trace_paths(self, o, d, pixel, sample, seed=0, n_bounces=5, math_mode=PT_MATH_PARITY, bsdf_model=PT_BSDF_REFERENCE):
         torch = _torch()
         n = o.shape[0]
         rgb = torch.zeros((n, 3), dtype=torch.float32, device=self._dev())
         with torch.cuda.device(self.device):
-            _check(lib.pt_trace_paths(self.h, _ptr(o), _ptr(d), _ptr(pixel), _ptr(sample), n, seed, n_bounces,
-                                      math_mode, _ptr(rgb), _stream()))
+            fn = lib.pt_trace_paths_alt if bsdf_model == PT_BSDF_CLASSES else lib.pt_trace_paths
+            _check(fn(self.h, _ptr(o), _ptr(d), _ptr(pixel), _ptr(sample), n, seed, n_bounces, math_mode, _ptr(rgb), _stream()))
         return rgb
 
 

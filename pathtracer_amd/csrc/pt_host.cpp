@@ -136,11 +136,16 @@ float len3(float x, float y, float z) { return sqrtf(x * x + y * y + z * z); }
 int bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, float* rec, FShade* fs, int32_t* ftype) {
     std::memset(fs, 0, sizeof(*fs));
     fs->type = p.type; fs->material = p.material;
-    float col[3][3], ncol[3][3];   // columns of L and their unit vectors
+    // Columns of L and the unit normals along them.  The reference forms a normal as normalize(T*axis - wOrigin)
+    // (shapes.h:127,161-167): adding the translation and taking it off again swallows components far below it, such as
+    // the 4e-8 a rotation by (float)(pi/2) leaves where a zero belongs.  The same arithmetic here gives the same signs,
+    // which matters wherever shading branches on the sign of a normal component.
+    float col[3][3], ncol[3][3];
     for (int j = 0; j < 3; j++) {
-        for (int i = 0; i < 3; i++) col[j][i] = fwd.m[i][j];
-        const float l = len3(col[j][0], col[j][1], col[j][2]);
-        for (int i = 0; i < 3; i++) ncol[j][i] = l > 0.0f ? col[j][i] / l : col[j][i];
+        float n[3];
+        for (int i = 0; i < 3; i++) { col[j][i] = fwd.m[i][j]; n[i] = (fwd.m[i][j] + fwd.m[i][3]) - fwd.m[i][3]; }
+        const float l = sqrtf(n[0] * n[0] + (n[1] * n[1] + n[2] * n[2]));
+        for (int i = 0; i < 3; i++) ncol[j][i] = l > 0.0f ? n[i] / l : n[i];
     }
     auto put_inv = [&]() { for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) rec[i * 4 + j] = inv.m[i][j]; };
     switch (p.type) {
@@ -491,6 +496,7 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     if (cfg->fb_layout != PT_FB_AOS && cfg->fb_layout != PT_FB_SOA) return PT_FAIL("pt_render: unknown fb_layout");
     if (cfg->row_step < 0) return PT_FAIL("pt_render: negative row_step");
     if (cfg->fb_compact != 0 && cfg->fb_compact != 1) return PT_FAIL("pt_render: fb_compact must be 0 or 1");
+    if (cfg->bsdf_model != PT_BSDF_REFERENCE && cfg->bsdf_model != PT_BSDF_CLASSES) return PT_FAIL("pt_render: unknown bsdf_model");
     PT_CHECK(hipSetDevice(sc->device));
     RenderArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -509,7 +515,7 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     }
     a.du = du[0]; a.dv = dv[1];
     a.max_x = cfg->max_x; a.max_y = cfg->max_y;
-    a.n_samples = cfg->n_samples; a.n_bounces = cfg->n_bounces;
+    a.n_samples = cfg->n_samples; a.n_bounces = cfg->n_bounces; a.bsdf_model = cfg->bsdf_model;
     a.seed_hash = host_hash(cfg->seed + 0x9E3779B9u);
     const int row_step = cfg->row_step == 0 ? 1 : cfg->row_step;
     a.row_begin = cfg->row_begin; a.row_step = row_step;
@@ -561,18 +567,32 @@ int pt_nearest_batch(const pt_scene* sc, const float* d_o, const float* d_d, int
     return ptk_nearest_batch(sc, d_o, d_d, n_rays, d_prim, d_t, d_pos, d_nrm, d_inside, (hipStream_t)stream);
 }
 
-int pt_trace_paths(const pt_scene* sc, const float* d_o, const float* d_d, const uint32_t* d_pixel,
-                   const uint32_t* d_sample, int n_rays, uint32_t seed, int n_bounces, int math_mode,
-                   float* d_rgb, void* stream) {
+static int trace_paths(const char* who, const pt_scene* sc, const float* d_o, const float* d_d, const uint32_t* d_pixel,
+                       const uint32_t* d_sample, int n_rays, uint32_t seed, int n_bounces, int math_mode, int bsdf_model,
+                       float* d_rgb, void* stream) {
     if (!sc || !d_o || !d_d || !d_pixel || !d_sample || !d_rgb || n_rays < 0 || n_bounces < 0)
-        return PT_FAIL("pt_trace_paths: bad arguments");
+        return pt_set_error(-1, who, __FILE__, __LINE__);
     PT_CHECK(hipSetDevice(sc->device));
     const uint32_t sh = host_hash(seed + 0x9E3779B9u);
     if (math_mode == PT_MATH_PARITY)
-        return ptk_trace_paths_parity(sc, d_o, d_d, d_pixel, d_sample, n_rays, sh, n_bounces, d_rgb, (hipStream_t)stream);
+        return ptk_trace_paths_parity(sc, d_o, d_d, d_pixel, d_sample, n_rays, sh, n_bounces, bsdf_model, d_rgb, (hipStream_t)stream);
     if (math_mode == PT_MATH_FAST)
-        return ptk_trace_paths_fast(sc, d_o, d_d, d_pixel, d_sample, n_rays, sh, n_bounces, d_rgb, (hipStream_t)stream);
-    return PT_FAIL("pt_trace_paths: unknown math_mode");
+        return ptk_trace_paths_fast(sc, d_o, d_d, d_pixel, d_sample, n_rays, sh, n_bounces, bsdf_model, d_rgb, (hipStream_t)stream);
+    return pt_set_error(-1, who, __FILE__, __LINE__);
+}
+
+int pt_trace_paths(const pt_scene* sc, const float* d_o, const float* d_d, const uint32_t* d_pixel,
+                   const uint32_t* d_sample, int n_rays, uint32_t seed, int n_bounces, int math_mode,
+                   float* d_rgb, void* stream) {
+    return trace_paths("pt_trace_paths: bad arguments or unknown math_mode", sc, d_o, d_d, d_pixel, d_sample, n_rays, seed,
+                       n_bounces, math_mode, PT_BSDF_REFERENCE, d_rgb, stream);
+}
+
+int pt_trace_paths_alt(const pt_scene* sc, const float* d_o, const float* d_d, const uint32_t* d_pixel,
+                       const uint32_t* d_sample, int n_rays, uint32_t seed, int n_bounces, int math_mode,
+                       float* d_rgb, void* stream) {
+    return trace_paths("pt_trace_paths_alt: bad arguments or unknown math_mode", sc, d_o, d_d, d_pixel, d_sample, n_rays, seed,
+                       n_bounces, math_mode, PT_BSDF_CLASSES, d_rgb, stream);
 }
 
 int pt_rng_draws(int device, uint32_t seed, uint32_t pixel, uint32_t sample, int n_slots,

@@ -118,6 +118,7 @@ struct RenderArgs {
     float du, dv;          // pixel_delta_u.x, pixel_delta_v.y
     int32_t max_x, max_y;
     int32_t n_samples, n_bounces;
+    int32_t bsdf_model;    // PT_BSDF_*
     uint32_t seed_hash;    // H(seed + 0x9E3779B9)
     int32_t row_begin, row_step, n_rows;   // rendered rows: row_begin + k*row_step, k in [0, n_rows)
     uint32_t n_lin;                        // n_rows * max_x: pixels of this launch, numbered row by row
@@ -150,9 +151,9 @@ int ptk_raypath_batch(const pt_scene* sc, int prim, const float* o, const float*
 int ptk_nearest_batch(const pt_scene* sc, const float* o, const float* d, int n, int32_t* prim, float* t,
                       float* pos, float* nrm, int32_t* inside, hipStream_t s);
 int ptk_trace_paths_parity(const pt_scene* sc, const float* o, const float* d, const uint32_t* pixel,
-                           const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, float* rgb, hipStream_t s);
+                           const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, int bsdf_model, float* rgb, hipStream_t s);
 int ptk_trace_paths_fast(const pt_scene* sc, const float* o, const float* d, const uint32_t* pixel,
-                         const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, float* rgb, hipStream_t s);
+                         const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, int bsdf_model, float* rgb, hipStream_t s);
 int ptk_rng_draws(uint32_t seed_hash, uint32_t pixel, uint32_t sample, int n_slots, uint32_t* bits, float* u, hipStream_t s);
 
 // Records "HIP error = <n> at <file>:<line> '<expr>'" for pt_last_error().

@@ -441,6 +441,67 @@ PTD bool path_shade(Path& p, const Best& b, const FShade* shade, const DMat* mat
     return p.seg <= n_bounces;
 }
 
+// The loop body of bsdf_alternative.h:158-217 after the nearest hit is known: Lambertian or SmoothDielectric by
+// Material::bsdfType; true = continue.  A Lambertian sample survives only above the surface (f = 0 otherwise, and the
+// roulette then always ends the path) with weight albedo * min(N.L, 1) / N.L.
+PTD bool path_shade_alt(Path& p, const Best& b, const FShade* shade, const DMat* mats, int n_bounces, PhaseClock& clk) {
+    if (b.id < 0) return false;
+    const Surf s = surface(b, p.o, p.d, shade);
+    const DMat& M = mats[s.material];
+    const V3 em = v3(M.emissive[0], M.emissive[1], M.emissive[2]);
+    PHASE(clk, 2);
+    if ((max3(em.x, em.y, em.z) > 0.0f) || (min3(em.x, em.y, em.z) < 0.0f)) p.contrib = v3(__builtin_fmaf(em.x, p.coef.x, p.contrib.x), __builtin_fmaf(em.y, p.coef.y, p.contrib.y), __builtin_fmaf(em.z, p.coef.z, p.contrib.z));
+    const uint32_t slot = 2u + 6u * (uint32_t)p.seg;
+    V3 ndir, w;
+    if (M.bsdfType == 1) {
+        const float ior = M.IOR;
+        float pr = fresnel_ratio(p.d, s.nrm, M.f0, s.inside ? ior : 1.0f, s.inside ? ior : 1.0f);
+        float pt = 1.0f - pr;
+        pr = M.f0 > 0.0f ? pr : 0.0f;
+        pt = M.transparency > 0.0f ? pt : 0.0f;
+        bool transmission = false;
+        ndir = v3(0.0f, 0.0f, 0.0f);
+        if (pr != 0.0f || pt != 0.0f) {
+            const float ndi = dot(s.nrm, p.d);
+            if (rng_u(p.key, slot) < pr * rcp(pr + pt)) {
+                ndir = unit_or_zero(madd(s.nrm, -2.0f * ndi, p.d));
+            } else {
+                transmission = true;
+                const float eta = s.inside ? ior : rcp(ior);
+                const float k = __builtin_fmaf(-eta * eta, __builtin_fmaf(-ndi, ndi, 1.0f), 1.0f);
+                if (!(k < 0.0f)) ndir = unit_or_zero(madd(s.nrm, -__builtin_fmaf(eta, ndi, fsqrt(k)), p.d * eta));
+            }
+        }
+        const float pdf = transmission ? pt : 1.0f - pt;
+        if (!(pdf > 0.0f)) return false;
+        w = v3(M.specularColor[0], M.specularColor[1], M.specularColor[2]) * rcp(pdf);
+    } else {
+        const V3 N = s.nrm;
+        const float sign = N.z < 0.0f ? -1.0f : 1.0f;
+        const float a = -rcp(sign + N.z);
+        const float bb = N.x * N.y * a;
+        const V3 ox = v3(__builtin_fmaf(sign * N.x * N.x, a, 1.0f), sign * bb, -sign * N.x);
+        const V3 oy = v3(bb, __builtin_fmaf(N.y * N.y, a, sign), -N.y);
+        const V3 r = sphere_point(rng_u(p.key, slot + 1u), rng_u(p.key, slot + 2u));
+        ndir = unit_or_zero(madd(ox, r.x, madd(oy, r.y, N * r.z)));
+        const float ndl = dot(N, ndir), ndv = -dot(N, p.d);
+        if (!(ndl > 0.0f) || !(ndv > 0.0f)) return false;
+        w = v3(M.albedo[0], M.albedo[1], M.albedo[2]) * (__builtin_fminf(ndl, 1.0f) * rcp(ndl));
+    }
+    PHASE(clk, 4);
+    p.coef = p.coef * w;
+    const float q = max3(p.coef.x, p.coef.y, p.coef.z);
+    if (q <= 0.0f) return false;
+    if (!(q >= 1.0f)) {
+        if (q < rng_u(p.key, slot + 5u)) return false;
+    }
+    p.coef = p.coef * rcp(q);
+    p.o = s.pos;
+    p.d = ndir;
+    p.seg++;
+    return p.seg <= n_bounces;
+}
+
 // What the nearest-hit search reads: the record array and runs of the primitives the loop tests, and the
 // hierarchy over the others (n_nodes = 0: none).
 struct SceneRefs {
@@ -454,12 +515,13 @@ struct SceneRefs {
 
 // One iteration of the tracePath loop (bsdf.h:78-166); true = continue.
 template <bool BVH>
-PTD bool path_step(Path& p, const SceneRefs& sc, const FShade* shade, const DMat* mats, int n_bounces, PhaseClock& clk) {
+PTD bool path_step(Path& p, const SceneRefs& sc, const FShade* shade, const DMat* mats, int n_bounces, int bsdf_model, PhaseClock& clk) {
     Best b = best_none();
     const float dd = dot(p.d, p.d), idd = rcp(dd);
     scan_runs(p.o, p.d, dd, idd, as_constant(sc.fdata), as_constant(sc.runs), 0, sc.n_runs, b);
     if (BVH) { int n = 0; walk_hierarchy(p.o, p.d, dd, idd, sc.nodes, sc.n_nodes, sc.bprims, b, n, 0x7fffffff); }
     PHASE(clk, 1);
+    if (bsdf_model == PT_BSDF_CLASSES) return path_shade_alt(p, b, shade, mats, n_bounces, clk);
     return path_shade(p, b, shade, mats, n_bounces, clk);
 }
 
@@ -476,7 +538,7 @@ struct WalkPath : Path {
 // (and start their next segment) once shade_gate of them have gathered or nobody is searching any more, so that
 // the shading code does not run for one or two lanes at a time.
 PTD bool path_step_walk(WalkPath& p, const SceneRefs& sc, const FShade* shade, const DMat* mats, int n_bounces,
-                        int walk_budget, int shade_gate, PhaseClock& clk) {
+                        int bsdf_model, int walk_budget, int shade_gate, PhaseClock& clk) {
     const float dd = dot(p.d, p.d), idd = rcp(dd);
     if (p.node < 0) {
         p.best = best_none();
@@ -489,6 +551,7 @@ PTD bool path_step_walk(WalkPath& p, const SceneRefs& sc, const FShade* shade, c
     const unsigned long long done_m = __ballot(done), busy_m = __ballot(!done);
     if (!done || (__popcll(done_m) < shade_gate && busy_m != 0ull)) return true;
     p.node = -1;
+    if (bsdf_model == PT_BSDF_CLASSES) return path_shade_alt(p, p.best, shade, mats, n_bounces, clk);
     return path_shade(p, p.best, shade, mats, n_bounces, clk);
 }
 
@@ -541,10 +604,10 @@ struct FastTracer {
         return step_path(p, sc, a, c);
     }
     static PTD bool step_path(ptf::Path& p, const SceneRefs& sc, const RenderArgs& a, FastCtx& c) {
-        return path_step<false>(p, sc, c.shade, c.mats, a.n_bounces, c.clk);
+        return path_step<false>(p, sc, c.shade, c.mats, a.n_bounces, a.bsdf_model, c.clk);
     }
     static PTD bool step_path(ptf::WalkPath& p, const SceneRefs& sc, const RenderArgs& a, FastCtx& c) {
-        return path_step_walk(p, sc, c.shade, c.mats, a.n_bounces, a.walk_budget, a.shade_gate, c.clk);
+        return path_step_walk(p, sc, c.shade, c.mats, a.n_bounces, a.bsdf_model, a.walk_budget, a.shade_gate, c.clk);
     }
     static PTD void idle(Path& p) {
         p.o = v3(0.0f, 0.0f, 0.0f); p.d = v3(0.0f, 0.0f, 0.0f);
@@ -568,6 +631,7 @@ struct FastTracer {
         return b;
     }
     static PTD bool shade(Path& p, const Best& b, const RenderArgs& a, FastCtx& c) {
+        if (a.bsdf_model == PT_BSDF_CLASSES) return path_shade_alt(p, b, c.shade, c.mats, a.n_bounces, c.clk);
         return path_shade(p, b, c.shade, c.mats, a.n_bounces, c.clk);
     }
     static PTD void radiance(const Path& p, float rgb[3]) { rgb[0] = p.contrib.x; rgb[1] = p.contrib.y; rgb[2] = p.contrib.z; }
@@ -637,7 +701,7 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(SceneRefs sc,
                                                          const FShade* __restrict__ shade, const DMat* __restrict__ mats,
                                                          const float* __restrict__ o, const float* __restrict__ d,
                                                          const uint32_t* __restrict__ pixel, const uint32_t* __restrict__ sample,
-                                                         int n, uint32_t seed_hash, int n_bounces, float* rgb) {
+                                                         int n, uint32_t seed_hash, int n_bounces, int bsdf_model, float* rgb) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Path p;
@@ -646,7 +710,7 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(SceneRefs sc,
     p.d = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     p.coef = v3(1.0f, 1.0f, 1.0f); p.contrib = v3(0.0f, 0.0f, 0.0f); p.seg = 0;
     PhaseClock clk;
-    while (path_step<BVH>(p, sc, shade, mats, n_bounces, clk)) {}
+    while (path_step<BVH>(p, sc, shade, mats, n_bounces, bsdf_model, clk)) {}
     rgb[3 * i] = p.contrib.x; rgb[3 * i + 1] = p.contrib.y; rgb[3 * i + 2] = p.contrib.z;
 }
 
@@ -688,19 +752,19 @@ int ptk_render_fast(const RenderArgs& a, int variant, hipStream_t s) {
 }
 
 int ptk_trace_paths_fast(const pt_scene* sc, const float* o, const float* d, const uint32_t* pixel,
-                         const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, float* rgb, hipStream_t s) {
+                         const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, int bsdf_model, float* rgb, hipStream_t s) {
     if (n <= 0) return 0;
     SceneRefs refs;
     if (sc->n_bnodes > 0) {
         refs.fdata = sc->d_fdata_top; refs.runs = sc->d_runs_top; refs.n_runs = sc->n_runs_top;
         refs.nodes = sc->d_bnodes; refs.bprims = sc->d_bprims; refs.n_nodes = sc->n_bnodes;
         hipLaunchKernelGGL(trace_fast_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, s, refs,
-                           sc->d_fshade, sc->d_mats, o, d, pixel, sample, n, seed_hash, n_bounces, rgb);
+                           sc->d_fshade, sc->d_mats, o, d, pixel, sample, n, seed_hash, n_bounces, bsdf_model, rgb);
     } else {
         refs.fdata = sc->d_fdata; refs.runs = sc->d_runs; refs.n_runs = sc->n_runs;
         refs.nodes = nullptr; refs.bprims = nullptr; refs.n_nodes = 0;
         hipLaunchKernelGGL(trace_fast_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, s, refs,
-                           sc->d_fshade, sc->d_mats, o, d, pixel, sample, n, seed_hash, n_bounces, rgb);
+                           sc->d_fshade, sc->d_mats, o, d, pixel, sample, n, seed_hash, n_bounces, bsdf_model, rgb);
     }
     PT_CHECK(hipGetLastError());
     return 0;

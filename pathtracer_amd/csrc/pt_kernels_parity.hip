@@ -21,6 +21,7 @@ struct ParityTracer {
         p.seg = 0;
     }
     static __device__ __forceinline__ bool step(Path& p, const RenderArgs& a, ParityCtx&) {
+        if (a.bsdf_model == PT_BSDF_CLASSES) return path_step_alt(p, a.prims, a.n_prims, a.mats, a.n_bounces);
         return path_step(p, a.prims, a.n_prims, a.mats, a.n_bounces);
     }
     static __device__ __forceinline__ void radiance(const Path& p, float rgb[3]) {
@@ -84,14 +85,15 @@ __global__ __launch_bounds__(256) void nearest_kernel(const DPrim* __restrict__ 
 __global__ __launch_bounds__(256) void trace_parity_kernel(const DPrim* __restrict__ prims, int n_prims, const DMat* __restrict__ mats,
                                                            const float* __restrict__ o, const float* __restrict__ d,
                                                            const uint32_t* __restrict__ pixel, const uint32_t* __restrict__ sample,
-                                                           int n, uint32_t seed_hash, int n_bounces, float* rgb) {
+                                                           int n, uint32_t seed_hash, int n_bounces, int bsdf_model, float* rgb) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Path p;
     p.key = rng_key(seed_hash, pixel[i], sample[i]);
     p.o = load3(o, i); p.d = load3(d, i);
     p.coef = v3(1.0f, 1.0f, 1.0f); p.contrib = v3(0.0f, 0.0f, 0.0f); p.seg = 0;
-    while (path_step(p, prims, n_prims, mats, n_bounces)) {}
+    if (bsdf_model == PT_BSDF_CLASSES) { while (path_step_alt(p, prims, n_prims, mats, n_bounces)) {} }
+    else { while (path_step(p, prims, n_prims, mats, n_bounces)) {} }
     store3(rgb, i, p.contrib);
 }
 
@@ -135,10 +137,10 @@ int ptk_nearest_batch(const pt_scene* sc, const float* o, const float* d, int n,
 }
 
 int ptk_trace_paths_parity(const pt_scene* sc, const float* o, const float* d, const uint32_t* pixel,
-                           const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, float* rgb, hipStream_t s) {
+                           const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, int bsdf_model, float* rgb, hipStream_t s) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(trace_parity_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sc->d_prims, sc->n_prims, sc->d_mats,
-                       o, d, pixel, sample, n, seed_hash, n_bounces, rgb);
+                       o, d, pixel, sample, n, seed_hash, n_bounces, bsdf_model, rgb);
     PT_CHECK(hipGetLastError());
     return 0;
 }

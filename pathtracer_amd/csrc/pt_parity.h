@@ -383,6 +383,77 @@ PTD bool path_step(Path& p, const DPrim* __restrict__ prims, int n_prims, const 
     return p.seg <= n_bounces;
 }
 
+// ---- bsdf_alternative.h: the class-based BSDFs and their tracePath -------------------------
+// Draw slots of segment s: 2+6s+{0 dielectric choice, 1,2 Lambertian u1,u2, 5 Russian roulette}.
+PTD void construct_onb(V3 N, V3* x, V3* y) {                                    // bsdf_alternative.h:9-18
+    float sign = (N.z < 0 ? -1.0f : 1.0f);
+    float a = -1 / (sign + N.z);
+    float b = N.x * N.y * a;
+    *x = v3(1 + sign * (N.x * N.x) * a, sign * b, -sign * N.x);
+    *y = v3(b, sign + (N.y * N.y) * a, -N.y);
+}
+
+// One iteration of the loop of bsdf_alternative.h:158-217; true = the path goes on.  The switch's `default:` case
+// (:195-199, which leaves the outer variables unset) is taken as Lambertian, and a SmoothDielectric with neither
+// reflection nor transmission (:131-132, `*transmission` unset) as transmission = false.
+PTD bool path_step_alt(Path& p, const DPrim* __restrict__ prims, int n_prims, const DMat* __restrict__ mats, int n_bounces) {
+    Hit h = nearest_hit(p.o, p.d, prims, n_prims);
+    if (h.prim < 0) return false;
+    const DMat& M = mats[prims[h.prim].material];
+    V3 emissive = v3(M.emissive[0], M.emissive[1], M.emissive[2]);
+    if (sqn(emissive) > 0.0f) p.contrib = p.contrib + emissive * p.coef;
+    const uint32_t slot = 2u + 6u * (uint32_t)p.seg;
+    V3 ndir, f;
+    float pdf;
+    if (M.bsdfType == 1) {                                                      // SmoothDielectric, :116-149
+        float ior = M.IOR;
+        float pr = fresnel_ratio(h.nrm, p.d, M.f0, 1.0f, h.inside ? ior : 1.0f, !h.inside ? 1.0f : ior);
+        float pt = 1 - pr;
+        pr *= (M.f0 > 0) ? 1.0f : 0.0f;
+        pt *= (M.transparency > 0) ? 1.0f : 0.0f;
+        bool transmission = false;
+        if (pr == 0.0f && pt == 0.0f) {
+            ndir = v3(0.0f, 0.0f, 0.0f);
+        } else {
+            float u = rng_u(p.key, slot);
+            if (u < pr / (pr + pt)) {
+                ndir = normalized(reflect(p.d, h.nrm));
+            } else {
+                transmission = true;
+                ndir = normalized(refract(p.d, h.nrm, h.inside ? ior : 1.0f / ior));
+            }
+        }
+        ndir = normalized(ndir);
+        f = v3(M.specularColor[0], M.specularColor[1], M.specularColor[2]);
+        pdf = transmission ? pt : 1 - pt;
+    } else {                                                                    // Lambertian, :74-114
+        float u1 = rng_u(p.key, slot + 1u), u2 = rng_u(p.key, slot + 2u);
+        V3 ox, oy;
+        construct_onb(h.nrm, &ox, &oy);
+        V3 res = sample_hemisphere(u1, u2);
+        ndir = normalized((res.x * ox + res.y * oy) + res.z * h.nrm);
+        V3 V = -1.0f * p.d;
+        float NDotL = dot(h.nrm, ndir), NDotV = dot(h.nrm, V);
+        if (NDotL <= 0.0f || NDotV <= 0.0f) {
+            f = v3(0.0f, 0.0f, 0.0f);
+        } else {
+            V3 out = (float)(1.0f / 3.14159265358979323846) * v3(M.albedo[0], M.albedo[1], M.albedo[2]);
+            f = out * fmaxf(fminf(NDotL, 1.0f), 0.0f);
+        }
+        pdf = (float)((double)fabsf(dot(ndir, h.nrm)) * (1.0f / 3.14159265358979323846));
+    }
+    if (pdf > 0.0f) p.coef = p.coef * (f / pdf);
+    else return false;
+    float pm = fmaxf(p.coef.x, fmaxf(p.coef.y, p.coef.z));
+    float u = rng_u(p.key, slot + 5u);
+    if (pm < u) return false;
+    p.coef = p.coef * (1 / pm);
+    p.o = h.pos;
+    p.d = ndir;
+    p.seg++;
+    return p.seg <= n_bounces;
+}
+
 // Camera ray of (pixel i,j; sample) exactly as render builds it (main.cu:62-64).
 PTD void camera_ray(const RenderArgs& a, int i, int j, uint32_t key, V3* o, V3* d) {
     float jx = rng_u(key, 0u), jy = rng_u(key, 1u);

@@ -2,7 +2,7 @@
 // scene with the Shape constructors, render through the C ABI, print the image as
 // ASCII PPM (P3) on stdout with scanline progress on stderr.  Every literal of
 // the reference's main() is a flag here whose default is that literal:
-//   --width 800 --height 800 --spp 2000 --depth 5 --seed 0 --math fast
+//   --width 800 --height 800 --spp 2000 --depth 5 --seed 0 --math fast --bsdf reference|classes
 //   --scene default|glass[N]|synthetic  --scene-file FILE  --format p3|p6|pfm  --gpus 1  --stats
 // Usage, as in the reference's readme:  pathtracer > out.ppm
 #include <chrono>
@@ -124,6 +124,7 @@ int main(int argc, char** argv) {
         else if (a == "--depth") opt.n_bounces = std::atoi(next());
         else if (a == "--seed") opt.seed = (unsigned)std::strtoul(next(), nullptr, 10);
         else if (a == "--math") opt.math_mode = std::string(next()) == "parity" ? PT_MATH_PARITY : PT_MATH_FAST;
+        else if (a == "--bsdf") opt.bsdf_model = std::string(next()) == "classes" ? PT_BSDF_CLASSES : PT_BSDF_REFERENCE;
         else if (a == "--scene") scene_name = next();
         else if (a == "--scene-file") scene_file = next();
         else if (a == "--format") format = next();

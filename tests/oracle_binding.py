@@ -32,7 +32,7 @@ class Config(C.Structure):
         ("camera_pos", C.c_float * 3), ("max_x", C.c_int), ("max_y", C.c_int),
         ("focal_length", C.c_float), ("view_port_height", C.c_float),
         ("n_samples", C.c_int), ("n_bounces", C.c_int), ("seed", C.c_uint),
-        ("row_begin", C.c_int), ("row_end", C.c_int),
+        ("row_begin", C.c_int), ("row_end", C.c_int), ("bsdf_model", C.c_int),
     ]
 
 
@@ -109,7 +109,7 @@ def focal_length(nx, ny, v_height=5.0, fov=45.0):
     return float(lib().oracle_focal_length(nx, ny, v_height, fov))
 
 
-def make_config(width, height, spp, n_bounces=5, seed=0, row_begin=0, row_end=None, camera=(0.0, 0.0, 0.0)):
+def make_config(width, height, spp, n_bounces=5, seed=0, row_begin=0, row_end=None, camera=(0.0, 0.0, 0.0), bsdf_model=0):
     cfg = Config()
     cfg.camera_pos[:] = camera
     cfg.max_x, cfg.max_y = width, height
@@ -118,6 +118,7 @@ def make_config(width, height, spp, n_bounces=5, seed=0, row_begin=0, row_end=No
     cfg.n_samples, cfg.n_bounces, cfg.seed = spp, n_bounces, seed
     cfg.row_begin = row_begin
     cfg.row_end = height if row_end is None else row_end
+    cfg.bsdf_model = bsdf_model
     return cfg
 
 
@@ -161,13 +162,13 @@ class Scene:
         self.L.oracle_nearest_batch(C.c_void_p(self.h), _fp(o), _fp(d), C.c_int(n), _fp(prim), _fp(t), _fp(pos), _fp(nrm), _fp(inside))
         return dict(prim=prim, t=t, pos=pos, nrm=nrm, inside=inside)
 
-    def trace_paths(self, o, d, pixel, sample, seed=0, n_bounces=5):
+    def trace_paths(self, o, d, pixel, sample, seed=0, n_bounces=5, bsdf_model=0):
         o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32)
         pixel = np.ascontiguousarray(pixel, np.uint32); sample = np.ascontiguousarray(sample, np.uint32)
         n = o.shape[0]
         rgb = np.zeros((n, 3), np.float32)
-        self.L.oracle_trace_paths(C.c_void_p(self.h), _fp(o), _fp(d), _fp(pixel), _fp(sample), C.c_int(n),
-                                  C.c_uint(seed), C.c_int(n_bounces), _fp(rgb))
+        fn = self.L.oracle_trace_paths_alt if bsdf_model == 1 else self.L.oracle_trace_paths
+        fn(C.c_void_p(self.h), _fp(o), _fp(d), _fp(pixel), _fp(sample), C.c_int(n), C.c_uint(seed), C.c_int(n_bounces), _fp(rgb))
         return rgb
 
 

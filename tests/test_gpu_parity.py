@@ -273,3 +273,52 @@ def test_render_1080p_properties(torch, pt):
     bad = ((a - p).abs().amax(dim=2) > 0.05).float().mean().item()
     print("1080p fast vs parity: fraction of pixels off by > 0.05: %.5f" % bad)
     assert bad <= 0.005
+
+
+def test_alternative_bsdf_model(torch, pt, oracle):
+    """tracePath of bsdf_alternative.h:153-219 (Lambertian / SmoothDielectric by Material::bsdfType), which the
+    reference ships but does not compile: parity-order kernel against the oracle's restatement path by path and as
+    an image, fast kernel against the same image statistically."""
+    prims, n, mats, nm = pt.default_scene()
+    sc = pt.Scene(prims, n, mats, nm)
+    osc = oracle.Scene(*oracle.default_scene())
+    rng = np.random.default_rng(21)
+    nr = 8192
+    o = np.zeros((nr, 3), np.float32)
+    d = rng.normal(size=(nr, 3)); d[:, 2] = -np.abs(d[:, 2]) - 0.5
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    px = rng.integers(0, 1 << 20, nr).astype(np.uint32); smp = rng.integers(0, 64, nr).astype(np.uint32)
+    ref = osc.trace_paths(o, d, px, smp, seed=3, n_bounces=5, bsdf_model=1)
+    args = [torch.from_numpy(x).cuda() for x in (o, d, px, smp)]
+    got = sc.trace_paths(*args, seed=3, n_bounces=5, math_mode=pt.PT_MATH_PARITY, bsdf_model=pt.PT_BSDF_CLASSES).cpu().numpy()
+    assert np.isfinite(got).all()
+    close = np.abs(got - ref).max(axis=1) <= 1e-4 * (1.0 + np.abs(ref).max(axis=1))
+    assert close.mean() >= 0.999, close.mean()
+    assert (ref.max(axis=1) > 0).mean() > 0.005           # some paths reach the light (half the Lambertian samples die per bounce)
+    # the model differs from bsdf.h's: same rays, different radiance
+    ref0 = osc.trace_paths(o, d, px, smp, seed=3, n_bounces=5, bsdf_model=0)
+    assert np.abs(ref0 - ref).max() > 1.0
+    # images
+    w, h, spp = 160, 100, 16
+    img_ref = osc.render(oracle.make_config(w, h, spp, bsdf_model=1))
+    par = sc.render(pt.make_config(w, h, spp, math_mode=pt.PT_MATH_PARITY, bsdf_model=pt.PT_BSDF_CLASSES)).cpu().numpy()
+    fast = sc.render(pt.make_config(w, h, spp, math_mode=pt.PT_MATH_FAST, bsdf_model=pt.PT_BSDF_CLASSES)).cpu().numpy()
+    mean = img_ref.mean()
+    rmse_p = np.sqrt(((par - img_ref) ** 2).mean()) / mean
+    bad_p = (np.abs(par - img_ref).max(axis=2) > 0.05).mean()
+    rmse_f = np.sqrt(((fast - img_ref) ** 2).mean()) / mean
+    bad_f = (np.abs(fast - img_ref).max(axis=2) > 0.05).mean()
+    print("alternative bsdf: parity rmse %.2e bad %.5f | fast rmse %.2e bad %.5f" % (rmse_p, bad_p, rmse_f, bad_f))
+    assert rmse_p <= 0.01 and bad_p <= 0.001               # the bar of the bsdf.h path: RMSE <= 1 % of the mean
+    assert bad_f <= 0.02
+    np.testing.assert_allclose(fast.mean(axis=(0, 1)), img_ref.mean(axis=(0, 1)), rtol=0.03)
+    # LDS-staged loop, hierarchy and explicit rays run the same shading code
+    a = sc.render(pt.make_config(w, h, spp, math_mode=pt.PT_MATH_FAST_SCALAR, bsdf_model=pt.PT_BSDF_CLASSES))
+    b = sc.render(pt.make_config(w, h, spp, math_mode=pt.PT_MATH_FAST_LDS, bsdf_model=pt.PT_BSDF_CLASSES))
+    assert torch.equal(a, b)
+    big = pt.Scene(*pt.synthetic_scene(300, 200, 5))
+    a = big.render(pt.make_config(96, 54, 4, math_mode=pt.PT_MATH_FAST, bsdf_model=pt.PT_BSDF_CLASSES))
+    b = big.render(pt.make_config(96, 54, 4, math_mode=pt.PT_MATH_FAST_SCALAR, bsdf_model=pt.PT_BSDF_CLASSES))
+    assert big.bvh_nodes > 0 and torch.equal(a, b)
+    with pytest.raises(pt.PtError):
+        sc.render(pt.make_config(8, 8, 1, bsdf_model=7))
