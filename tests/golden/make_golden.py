@@ -99,7 +99,18 @@ def main():
     # default scene, 256x256 @ 16 spp, seed 0 (config 1)
     fb = sc.render(cfg)
     np.savez_compressed(os.path.join(HERE, "default_256x256_16spp.npz"), fb=fb)
+    alternative_bsdf()
     print("wrote golden vectors:", sorted(os.listdir(HERE)))
+
+
+def alternative_bsdf():
+    """Radiance of the rays of default_scene_paths.npz under the tracePath of bsdf_alternative.h, plus a 96x64@32 image."""
+    g = np.load(os.path.join(HERE, "default_scene_paths.npz"))
+    prims, n, mats, nm = ob.default_scene()
+    sc = ob.Scene(prims, n, mats, nm)
+    rgb = sc.trace_paths(g["o"], g["d"], g["pixel"], g["sample"], seed=0, n_bounces=5, bsdf_model=1)
+    fb = sc.render(ob.make_config(96, 64, 32, bsdf_model=1))
+    np.savez_compressed(os.path.join(HERE, "alternative_bsdf.npz"), rgb=rgb, fb=fb)
 
 
 if __name__ == "__main__":

@@ -111,6 +111,31 @@ def test_default_scene_golden(oracle):
     np.testing.assert_allclose(rgb, g["rgb"], rtol=1e-5, atol=1e-6)
 
 
+def test_alternative_bsdf_golden(oracle):
+    """tracePath of bsdf_alternative.h:153-219 in the oracle: committed vectors and what the text implies."""
+    ob = oracle
+    sc = ob.Scene(*ob.default_scene())
+    g = np.load(os.path.join(GOLD, "default_scene_paths.npz"))
+    a = np.load(os.path.join(GOLD, "alternative_bsdf.npz"))
+    rgb = sc.trace_paths(g["o"], g["d"], g["pixel"], g["sample"], seed=0, n_bounces=5, bsdf_model=1)
+    np.testing.assert_allclose(rgb, a["rgb"], rtol=1e-5, atol=1e-6)
+    fb = sc.render(ob.make_config(96, 64, 32, bsdf_model=1))
+    np.testing.assert_allclose(fb, a["fb"], rtol=1e-5, atol=1e-6)
+    # depth 0: only light seen directly, the same under both models
+    r0 = sc.trace_paths(g["o"], g["d"], g["pixel"], g["sample"], n_bounces=0, bsdf_model=0)
+    r1 = sc.trace_paths(g["o"], g["d"], g["pixel"], g["sample"], n_bounces=0, bsdf_model=1)
+    assert np.array_equal(r0, r1) and r0.max() == 20.0
+    # Lambertian weight f/pdf is the albedo (N.L <= 1) and the roulette renormalises by its maximum, so a path that
+    # reaches the light after diffuse bounces carries emissive x (products of albedo / max albedo): for the grey,
+    # red and green walls every channel of the radiance is 0 or one of the light's (20, 18, 14)
+    lit = rgb[(rgb.max(axis=1) > 0) & (g["prim"] != 5) & (g["prim"] < 7)]
+    assert len(lit) > 10
+    assert np.all((np.abs(lit) < 1e-6) | (np.abs(lit - np.array([20.0, 18.0, 14.0], np.float32)) < 1e-3))
+    # the class model has no Beer term and other weights: it is not the bsdf.h image
+    fb0 = sc.render(ob.make_config(96, 64, 32, bsdf_model=0))
+    assert abs(fb0.mean() - fb.mean()) > 0.05
+
+
 def test_render_golden_and_tiling(oracle):
     ob = oracle
     prims, n, mats, nm = ob.default_scene()
