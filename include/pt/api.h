@@ -268,7 +268,7 @@ inline IntersectionPoint getNearestIntersection(const ray& r, Shape** scene, int
 // bsdf.h:73-168 for n rays; ray i draws from stream s[i] starting after the two
 // camera-jitter slots.  n_bounces defaults to the reference's literal (bsdf.h:75).
 inline void tracePath_batch(const pt::DeviceScene& sc, const ray* rays, const pt_rng* s, int n, vec3* out,
-                            int n_bounces = 5, int math_mode = PT_MATH_PARITY) {
+                            int n_bounces = 5, int math_mode = PT_MATH_PARITY, int bsdf_model = PT_BSDF_REFERENCE) {
     if (n <= 0) return;
     std::vector<float> o((size_t)n * 3), d((size_t)n * 3);
     std::vector<uint32_t> px(n), sm(n);
@@ -278,7 +278,10 @@ inline void tracePath_batch(const pt::DeviceScene& sc, const ray* rays, const pt
     }
     pt::DeviceBuffer<float> d_o(o.data(), o.size()), d_d(d.data(), d.size()), d_rgb((size_t)n * 3);
     pt::DeviceBuffer<uint32_t> d_px(px.data(), px.size()), d_sm(sm.data(), sm.size());
-    checkHipErrors(pt_trace_paths(sc.handle(), d_o.p, d_d.p, d_px.p, d_sm.p, n, s[0].seed, n_bounces, math_mode, d_rgb.p, nullptr));
+    if (bsdf_model == PT_BSDF_CLASSES)
+        checkHipErrors(pt_trace_paths_alt(sc.handle(), d_o.p, d_d.p, d_px.p, d_sm.p, n, s[0].seed, n_bounces, math_mode, d_rgb.p, nullptr));
+    else
+        checkHipErrors(pt_trace_paths(sc.handle(), d_o.p, d_d.p, d_px.p, d_sm.p, n, s[0].seed, n_bounces, math_mode, d_rgb.p, nullptr));
     checkHipErrors(hipDeviceSynchronize());
     std::vector<float> rgb((size_t)n * 3);
     d_rgb.to_host(rgb.data());
@@ -288,10 +291,16 @@ inline void tracePath_batch(const pt::DeviceScene& sc, const ray* rays, const pt
 // bsdf.h:73 — the reference signature.  The reference mutates `r` as the path
 // advances and returns the radiance; only the radiance is observable to callers
 // (main.cu:65), so `r` is left as passed.
+// A host that includes bsdf_alternative.h instead of bsdf.h gets that file's tracePath (:153-219) under the same
+// name; here that choice is the macro PT_USE_BSDF_ALTERNATIVE, defined before this header is included.
 inline vec3 tracePath(Shape** scene, int n_objects, ray& r, pt_rng* s, int n_bounces = 5) {
     pt::DeviceScene sc(scene, n_objects);
     vec3 out;
+#ifdef PT_USE_BSDF_ALTERNATIVE
+    tracePath_batch(sc, &r, s, 1, &out, n_bounces, PT_MATH_PARITY, PT_BSDF_CLASSES);
+#else
     tracePath_batch(sc, &r, s, 1, &out, n_bounces);
+#endif
     return out;
 }
 
