@@ -5,8 +5,9 @@ A step is one render of the reference's default scene at 1920x1080, 64 spp,
 depth 5, seed 0 (BASELINE.json configs[1]) through pt_render of libpt_hip.so.
 With N GPUs (one process per GPU, torch.distributed "nccl" = RCCL) rank r renders
 rows r, r+N, ... of the same frame and the tiles are all-gathered over xGMI inside
-the timed region (two frames in flight: the gather of frame k overlaps the render
-of frame k+1), so total work is fixed: "strong" scaling.
+the timed region (two frames in flight on alternating streams: the gather of frame
+k overlaps the render of frame k+1, whose first waves also fill the compute units
+that frame k's last waves leave idle), so total work is fixed: "strong" scaling.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -85,6 +86,8 @@ def main():
     ap.add_argument("--math", choices=["fast", "parity", "scalar", "lds"], default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: gather each frame before rendering the next")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="development aid on one GPU: render rank 0's share of an N-GPU run with the N-GPU pipeline, no collectives")
     args = ap.parse_args()
 
     import torch
@@ -94,6 +97,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    emulate = args.emulate_world if world == 1 else 0
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
@@ -109,33 +113,39 @@ def main():
     scene = pt.Scene(prims, n, mats, nm, device=local_rank)
     math_mode = {"fast": pt.PT_MATH_FAST, "parity": pt.PT_MATH_PARITY, "scalar": pt.PT_MATH_FAST_SCALAR, "lds": pt.PT_MATH_FAST_LDS}[args.math]
     # rank r renders rows r, r+N, ... into a compact tile; all-gather + strided copy rebuild the image
-    my_rows = len(multigpu.rank_rows(HEIGHT, rank, world))
-    cfg = pt.make_config(WIDTH, HEIGHT, SPP, n_bounces=DEPTH, seed=SEED, row_begin=rank, row_end=HEIGHT, row_step=world,
+    part = emulate or world              # ranks the frame is split over
+    my_rows = len(multigpu.rank_rows(HEIGHT, rank, part))
+    cfg = pt.make_config(WIDTH, HEIGHT, SPP, n_bounces=DEPTH, seed=SEED, row_begin=rank, row_end=HEIGHT, row_step=part,
                          fb_compact=1, math_mode=math_mode)
-    # PT_BENCH_FORCE_OVERLAP=1 exercises the two-stream pipeline on one GPU (development aid)
-    overlap = (world > 1 or os.environ.get("PT_BENCH_FORCE_OVERLAP") == "1") and not args.no_overlap
-    frames = [multigpu.TiledFrame(HEIGHT, WIDTH, world, device) for _ in range(2 if overlap else 1)]
+    # PT_BENCH_FORCE_OVERLAP=1 exercises the pipeline on one GPU (development aid)
+    overlap = (part > 1 or os.environ.get("PT_BENCH_FORCE_OVERLAP") == "1") and not args.no_overlap
+    frames = [multigpu.TiledFrame(HEIGHT, WIDTH, part, device, collective=not emulate) for _ in range(2 if overlap else 1)]
     main_stream = torch.cuda.current_stream()
     comm_stream = torch.cuda.Stream(device=device) if overlap else None
+    # With frames in flight, consecutive frames render on alternating streams: the next frame's first waves fill
+    # the compute units the previous frame's last waves leave idle (a rank's share of the frame is a small launch).
+    render_streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)] if overlap else [main_stream]
     gathered_ev = [None, None]
 
     def step(k, ev_pair=None):
         """One frame: render this rank's rows, then gather.  With two frames in flight the gather of frame k runs on
         a second stream while frame k+1 renders; frame k's buffers are reused by frame k+2 only after its gather."""
         f = frames[k % len(frames)]
+        rs = render_streams[k % len(render_streams)]
         if overlap and gathered_ev[k % 2] is not None:
-            main_stream.wait_event(gathered_ev[k % 2])
-        if ev_pair:
-            ev_pair[0].record(main_stream)
-        if my_rows:
-            scene.render(cfg, out=f.local)
-        if ev_pair:
-            ev_pair[1].record(main_stream)
+            rs.wait_event(gathered_ev[k % 2])
+        with torch.cuda.stream(rs):
+            if ev_pair:
+                ev_pair[0].record(rs)
+            if my_rows:
+                scene.render(cfg, out=f.local)
+            if ev_pair:
+                ev_pair[1].record(rs)
         if not overlap:
             f.gather()
             return
         done = torch.cuda.Event()
-        done.record(main_stream)
+        done.record(rs)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(done)
             f.gather()
@@ -148,6 +158,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if overlap:
+        for rs in render_streams:
+            rs.wait_stream(main_stream)      # scene upload and buffer fills were issued on the current stream
     for k in range(args.warmup):
         step(k)
     fence()
@@ -170,8 +183,13 @@ def main():
     if rank == 0:
         total_samples = WIDTH * HEIGHT * SPP
         fps = flops_per_sample()
+        if emulate:
+            total_samples = my_rows * WIDTH * SPP     # one rank's share: the line is not a whole-job figure
         tile_samples = my_rows * WIDTH * SPP
-        achieved = fps * tile_samples / (kernel_ms * 1e-3) / 1e12
+        # Frames in flight render concurrently (alternating streams), so one launch's event-to-event time overlaps
+        # its neighbour's; the launch rate is then what prices the kernel: algorithmic flops per launch / time per step.
+        launch_ms = elapsed / args.steps * 1e3 if overlap else kernel_ms
+        achieved = fps * tile_samples / (launch_ms * 1e-3) / 1e12
         out = {
             "metric": "Msamples/sec at 1080p 64spp",
             "value": total_samples * args.steps / elapsed / 1e6,
@@ -181,13 +199,14 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "reference default scene (main.cu:73-195), 1920x1080, 64 spp, depth 5, seed 0",
-                       "math_mode": args.math, "partition": "rows r, r+%d, ... per rank, all-gather + strided copy%s" % (world, ", gather of frame k overlapped with render of frame k+1" if overlap else ""),
+                       "math_mode": args.math, "partition": "rows r, r+%d, ... per rank, all-gather + strided copy%s%s" % (part, ", gather of frame k overlapped with render of frame k+1, frames on alternating streams" if overlap else "", " [EMULATED rank 0 of %d on one GPU, no collectives]" % emulate if emulate else ""),
                        "flops_per_sample": fps},
             "roofline": {"bound": "valu_fp32", "kernel": {"fast": "render_fast_kernel", "scalar": "render_fast_kernel", "lds": "render_fast_tiled_kernel", "parity": "render_parity_kernel"}[args.math],
                          "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VALU_PEAK_TFLOPS,
                          "traffic": measured_traffic_bytes("render_fast_kernel" if args.math in ("fast", "scalar") else args.math) if world == 1 else None,
-                         "kernel_ms": kernel_ms, "kernel_msamples_per_s": tile_samples / kernel_ms / 1e3},
+                         "kernel_ms": kernel_ms, "kernel_msamples_per_s": tile_samples / launch_ms / 1e3,
+                         "launches_overlap": bool(overlap)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity_vs_oracle"] = cpu_baseline(image)

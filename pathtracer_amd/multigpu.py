@@ -26,8 +26,9 @@ def rank_rows(height, rank, world):
 class TiledFrame:
     """Buffers of one frame in flight: the local compact tile, the gathered tiles and the assembled image."""
 
-    def __init__(self, height, width, world, device):
+    def __init__(self, height, width, world, device, collective=True):
         self.height, self.width, self.world = height, width, world
+        self.collective = collective     # False: development runs of one rank's pipeline without a process group
         self.rows = tile_rows(height, world)
         self.local = torch.zeros((self.rows, width, 3), dtype=torch.float32, device=device)
         if world == 1:
@@ -41,7 +42,10 @@ class TiledFrame:
         """All-gather the local tiles and put the rows back in image order."""
         if self.world == 1:
             return self.image
-        dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=group)
+        if self.collective:
+            dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=group)
+        else:
+            self.gathered.view(self.world, -1)[0].copy_(self.local.view(-1))
         # gathered[r, k] is image row k*world + r
         ordered = self.gathered.view(self.world, self.rows, self.width, 3).permute(1, 0, 2, 3).reshape(self.world * self.rows, self.width, 3)
         self.image.copy_(ordered[:self.height])
