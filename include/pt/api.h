@@ -321,6 +321,8 @@ struct render_options {
     unsigned seed = 0;
     int row_begin = 0;
     int row_end = -1;            // -1 = max_y
+    int row_step = 1;            // rows row_begin, row_begin + row_step, ... are rendered
+    int fb_compact = 0;          // 1: the k-th rendered row is written as row k of fb
     int math_mode = PT_MATH_FAST;
     int bsdf_model = PT_BSDF_REFERENCE;   // PT_BSDF_CLASSES: tracePath of bsdf_alternative.h
     int device = 0;
@@ -335,7 +337,7 @@ inline pt_config pt_make_config(const config_t& config, const render_options& op
     c.n_samples = opt.n_samples; c.n_bounces = opt.n_bounces; c.seed = opt.seed;
     c.row_begin = opt.row_begin; c.row_end = opt.row_end < 0 ? config.max_y : opt.row_end;
     c.fb_layout = PT_FB_AOS; c.math_mode = opt.math_mode;
-    c.row_step = 1; c.fb_compact = 0; c.bsdf_model = opt.bsdf_model;
+    c.row_step = opt.row_step; c.fb_compact = opt.fb_compact; c.bsdf_model = opt.bsdf_model;
     return c;
 }
 

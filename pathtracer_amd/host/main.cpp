@@ -4,6 +4,7 @@
 // the reference's main() is a flag here whose default is that literal:
 //   --width 800 --height 800 --spp 2000 --depth 5 --seed 0 --math fast --bsdf reference|classes
 //   --scene default|glass[N]|synthetic  --scene-file FILE  --format p3|p6|pfm  --gpus 1  --stats
+//   --tiles T (default = gpus): the image is split into T interleaved row sets, set k rendered on GPU k % gpus
 // Usage, as in the reference's readme:  pathtracer > out.ppm
 #include <chrono>
 #include <cmath>
@@ -111,7 +112,7 @@ static int shapesFromTable(const std::vector<pt_prim>& prims, const std::vector<
 }
 
 int main(int argc, char** argv) {
-    int nx = 800, ny = 800, n_gpus = 1;
+    int nx = 800, ny = 800, n_gpus = 1, n_tiles = 0;
     render_options opt;                 // n_samples 2000, n_bounces 5 as in the reference
     std::string scene_name = "default", scene_file, format = "p3";
     bool stats = false;
@@ -129,6 +130,7 @@ int main(int argc, char** argv) {
         else if (a == "--scene-file") scene_file = next();
         else if (a == "--format") format = next();
         else if (a == "--gpus") n_gpus = std::atoi(next());
+        else if (a == "--tiles") n_tiles = std::atoi(next());
         else if (a == "--stats") stats = true;
         else { std::cerr << "unknown flag " << a << "\n"; return 2; }
     }
@@ -182,21 +184,24 @@ int main(int argc, char** argv) {
     float focal_length = (v_width / 2) / tan(DEG_TO_RAD(fov / 2));
     config_t config = {vec3(0, 0, 0), nx, ny, focal_length, v_height};
 
-    /* Render: GPU g owns rows [g*rows, (g+1)*rows); every tile lands in the host image */
+    /* Render: row set k = rows k, k + n_tiles, ... (rows through the glass cost more than wall rows, so interleaving
+       balances the devices) goes to GPU k % n_gpus, rendered into a compact tile; a strided copy puts it into the
+       host image */
+    if (n_tiles < n_gpus) n_tiles = n_gpus;
     const size_t num_pixels = (size_t)nx * ny;
     std::vector<vec3> fb(num_pixels);
-    const int rows = (ny + n_gpus - 1) / n_gpus;
-    std::vector<double> ms(n_gpus, 0.0);
-    auto worker = [&](int g) {
+    std::vector<double> ms(n_tiles, 0.0);
+    auto worker = [&](int k) {
+        const int g = k % n_gpus;
         checkHipErrors(hipSetDevice(g));
         render_options o = opt;
         o.device = g;
-        o.row_begin = std::min(ny, g * rows);
-        o.row_end = std::min(ny, o.row_begin + rows);
-        if (o.row_end <= o.row_begin) return;
+        o.row_begin = k; o.row_end = ny; o.row_step = n_tiles; o.fb_compact = 1;
+        const int my_rows = k < ny ? (ny - k + n_tiles - 1) / n_tiles : 0;
+        if (my_rows == 0) return;
         pt::DeviceScene dscene(scene.data(), n_objs, g);
         vec3* d_fb = nullptr;
-        checkHipErrors(hipMalloc((void**)&d_fb, num_pixels * sizeof(vec3)));
+        checkHipErrors(hipMalloc((void**)&d_fb, (size_t)my_rows * nx * sizeof(vec3)));
         hipEvent_t e0, e1;
         checkHipErrors(hipEventCreate(&e0)); checkHipErrors(hipEventCreate(&e1));
         checkHipErrors(hipEventRecord(e0, nullptr));
@@ -206,13 +211,13 @@ int main(int argc, char** argv) {
         checkHipErrors(hipDeviceSynchronize());
         float t = 0.0f;
         checkHipErrors(hipEventElapsedTime(&t, e0, e1));
-        ms[g] = t;
-        const size_t off = (size_t)o.row_begin * nx, cnt = (size_t)(o.row_end - o.row_begin) * nx;
-        checkHipErrors(hipMemcpy(fb.data() + off, d_fb + off, cnt * sizeof(vec3), hipMemcpyDeviceToHost));
+        ms[k] = t;
+        const size_t row_bytes = (size_t)nx * sizeof(vec3);
+        checkHipErrors(hipMemcpy2D(fb.data() + (size_t)k * nx, row_bytes * n_tiles, d_fb, row_bytes, row_bytes, my_rows, hipMemcpyDeviceToHost));
         checkHipErrors(hipFree(d_fb));
     };
     std::vector<std::thread> threads;
-    for (int g = 1; g < n_gpus; g++) threads.emplace_back(worker, g);
+    for (int k = 1; k < n_tiles; k++) threads.emplace_back(worker, k);
     worker(0);
     for (auto& t : threads) t.join();
 

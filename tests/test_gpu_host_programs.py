@@ -58,3 +58,18 @@ def test_host_program_scene_file_and_binary_formats():
     assert p6.returncode == 0 and p6.stdout == pt.ppm_p6(img)
     pf = subprocess.run([_need("pathtracer")] + args + ["--format", "pfm"], capture_output=True, timeout=120)
     assert pf.returncode == 0 and pf.stdout == pt.pfm(img)
+
+
+def test_host_program_interleaved_tiles_and_alternative_bsdf():
+    """The multi-GPU split of the C++ program (interleaved row sets, compact tiles, strided copy into the host image)
+    on one device: any number of row sets gives the same file; --bsdf classes is pt_config.bsdf_model = 1."""
+    import pathtracer_amd as pt
+    args = ["--width", "80", "--height", "50", "--spp", "4", "--format", "pfm"]
+    one = subprocess.run([_need("pathtracer")] + args, capture_output=True, timeout=120)
+    assert one.returncode == 0
+    for tiles in ("3", "7", "64"):
+        r = subprocess.run([_need("pathtracer")] + args + ["--tiles", tiles], capture_output=True, timeout=120)
+        assert r.returncode == 0 and r.stdout == one.stdout, tiles
+    alt = subprocess.run([_need("pathtracer")] + args + ["--bsdf", "classes", "--tiles", "2"], capture_output=True, timeout=120)
+    img = pt.Scene(*pt.default_scene()).render(pt.make_config(80, 50, 4, bsdf_model=pt.PT_BSDF_CLASSES)).cpu().numpy()
+    assert alt.returncode == 0 and alt.stdout == pt.pfm(img) and alt.stdout != one.stdout
