@@ -61,12 +61,15 @@ def build(force=False):
 _libs = {}
 
 
-def lib(count=False):
-    name = "liboracle_count.so" if count else "liboracle.so"
+def lib(count=False, variant=None):
+    """The oracle library: plain, with event counters (count), or another compiler's build (variant="clang")."""
+    name = "liboracle_%s.so" % variant if variant else ("liboracle_count.so" if count else "liboracle.so")
     if name not in _libs:
         path = os.path.join(ORACLE_DIR, name)
         if not os.path.exists(path):
-            build()
+            build(force=variant is not None)
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
         L = C.CDLL(path)
         L.oracle_scene_create.restype = C.c_void_p
         L.oracle_scene_create.argtypes = [C.POINTER(Prim), C.c_int, C.POINTER(Material), C.c_int]
@@ -125,8 +128,8 @@ def make_config(width, height, spp, n_bounces=5, seed=0, row_begin=0, row_end=No
 class Scene:
     """Owns an oracle scene built from flat (Prim[], Material[]) arrays."""
 
-    def __init__(self, prims, n, mats, n_mats, count=False):
-        self.L = lib(count)
+    def __init__(self, prims, n, mats, n_mats, count=False, variant=None):
+        self.L = lib(count, variant)
         self.prims, self.n, self.mats, self.n_mats = prims, n, mats, n_mats
         self.h = self.L.oracle_scene_create(prims, n, mats, n_mats)
         if not self.h:

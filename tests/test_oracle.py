@@ -2,6 +2,7 @@
 (tests/shape_test.cc), hand-derivable distances for the same rays, and the
 committed golden vectors.  No GPU."""
 import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -134,6 +135,31 @@ def test_alternative_bsdf_golden(oracle):
     # the class model has no Beer term and other weights: it is not the bsdf.h image
     fb0 = sc.render(ob.make_config(96, 64, 32, bsdf_model=0))
     assert abs(fb0.mean() - fb.mean()) > 0.05
+
+
+def test_host_compiler_noise_floor(oracle):
+    """The oracle built by g++ and by ROCm's clang++ (both -ffp-contract=off): how much of a difference between
+    kernel and oracle could be the host compiler's doing?  Intersection distances and hit records must agree bit for
+    bit (only +, -, *, /, sqrt, all correctly rounded); radiance goes through libm's sinf/cosf/expf, the same library
+    for both builds, so it agrees too."""
+    ob = oracle
+    try:
+        ob.lib(variant="clang")
+    except (FileNotFoundError, OSError, subprocess.CalledProcessError):
+        pytest.skip("no clang++ build of the oracle (oracle/Makefile builds it when /opt/rocm/lib/llvm/bin/clang++ exists)")
+    prims, n, mats, nm = ob.default_scene()
+    a, b = ob.Scene(prims, n, mats, nm), ob.Scene(prims, n, mats, nm, variant="clang")
+    g = np.load(os.path.join(GOLD, "default_scene_paths.npz"))
+    na, nb = a.nearest(g["o"], g["d"]), b.nearest(g["o"], g["d"])
+    for k in ("prim", "inside"):
+        assert np.array_equal(na[k], nb[k])
+    for k in ("t", "pos", "nrm"):
+        assert np.array_equal(na[k].view(np.uint32), nb[k].view(np.uint32)), k
+    ra = a.trace_paths(g["o"], g["d"], g["pixel"], g["sample"])
+    rb = b.trace_paths(g["o"], g["d"], g["pixel"], g["sample"])
+    assert np.array_equal(ra.view(np.uint32), rb.view(np.uint32))
+    cfg = ob.make_config(96, 64, 8)
+    assert np.array_equal(a.render(cfg).view(np.uint32), b.render(cfg).view(np.uint32))
 
 
 def test_render_golden_and_tiling(oracle):
