@@ -18,3 +18,16 @@ def oracle():
     import oracle_binding as ob
     ob.build()
     return ob
+
+
+@pytest.fixture(scope="session")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    return torch
+
+
+@pytest.fixture(scope="session")
+def pt():
+    import pathtracer_amd
+    return pathtracer_amd

@@ -1,0 +1,76 @@
+"""Properties checked at BASELINE's full sizes (1920x1080, 64 spp), where the oracle can only follow on a subset:
+independence of the row split, parity with the oracle on a row subset of the full frame, hierarchy == loop on the
+10 000-primitive scene, finite and energy-consistent images for the depth-31 glass scene."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W, H, SPP = 1920, 1080, 64
+
+
+def test_full_frame_is_independent_of_the_row_split(torch, pt):
+    sc = pt.Scene(*pt.default_scene())
+    full = sc.render(pt.make_config(W, H, SPP))
+    assert torch.isfinite(full).all()
+    # 8 interleaved row sets into compact tiles, as 8 GPUs would render them
+    out = torch.zeros_like(full)
+    for r in range(8):
+        tile = sc.render(pt.make_config(W, H, SPP, row_begin=r, row_step=8, fb_compact=1))
+        out[r::8] = tile
+    assert torch.equal(out, full)
+    # 4 contiguous row tiles written in place
+    out.zero_()
+    for r in range(4):
+        sc.render(pt.make_config(W, H, SPP, row_begin=r * 270, row_end=(r + 1) * 270), out=out)
+    assert torch.equal(out, full)
+    # another seed is another image with the same mean radiance (0.5 % is the bound set for converged statistics)
+    other = sc.render(pt.make_config(W, H, SPP, seed=1))
+    assert not torch.equal(other, full)
+    m0, m1 = full.double().mean(dim=(0, 1)), other.double().mean(dim=(0, 1))
+    assert float(((m0 - m1).abs() / m0).max()) < 0.005
+
+
+def test_full_frame_rows_against_the_oracle(torch, pt, oracle):
+    """Every 40th row of the full 1080p frame at 64 spp: parity-order kernel and fast kernel against the oracle."""
+    rows = np.arange(7, H, 40, dtype=np.int32)
+    osc = oracle.Scene(*oracle.default_scene())
+    ref = osc.render(oracle.make_config(W, H, SPP), rows=rows)[rows]
+    sc = pt.Scene(*pt.default_scene())
+    par = sc.render(pt.make_config(W, H, SPP, row_begin=7, row_step=40, fb_compact=1, math_mode=pt.PT_MATH_PARITY)).cpu().numpy()
+    fast = sc.render(pt.make_config(W, H, SPP, row_begin=7, row_step=40, fb_compact=1, math_mode=pt.PT_MATH_FAST)).cpu().numpy()
+    assert par.shape == ref.shape == fast.shape
+    mean = ref.mean()
+    rmse_p = np.sqrt(((par - ref) ** 2).mean()) / mean
+    rmse_f = np.sqrt(((fast - ref) ** 2).mean()) / mean
+    bad_p = (np.abs(par - ref).max(axis=2) > 0.05).mean()
+    bad_f = (np.abs(fast - ref).max(axis=2) > 0.05).mean()
+    print("1080p@64 rows: parity rmse %.2e bad %.5f | fast rmse %.2e bad %.5f" % (rmse_p, bad_p, rmse_f, bad_f))
+    assert rmse_p <= 0.01 and bad_p <= 1e-3            # the bar for the parity build: RMSE <= 1 % of the mean, <= 0.1 % of pixels off (a path whose sinf/cosf/expf differs in the last bit from the host's can take another branch)
+    assert rmse_f <= 0.03 and bad_f <= 0.003           # bar: RMSE of a few % of the mean, <= 0.3 % of pixels off by > 0.05
+    np.testing.assert_allclose(fast.mean(axis=(0, 1)), ref.mean(axis=(0, 1)), rtol=0.005)
+
+
+def test_10k_primitives_hierarchy_equals_loop_at_full_width(torch, pt):
+    sc = pt.Scene(*pt.synthetic_scene(5000, 4989, 12345))
+    assert sc.n == 10000 and sc.bvh_nodes > 0
+    a = sc.render(pt.make_config(W, H, SPP, row_begin=3, row_step=90, fb_compact=1, math_mode=pt.PT_MATH_FAST))
+    b = sc.render(pt.make_config(W, H, SPP, row_begin=3, row_step=90, fb_compact=1, math_mode=pt.PT_MATH_FAST_SCALAR))
+    assert a.shape[0] == 12 and torch.isfinite(a).all() and torch.equal(a, b)
+    # the whole frame through the hierarchy: finite, and its rows are the rows rendered alone
+    full = sc.render(pt.make_config(W, H, SPP))
+    assert torch.isfinite(full).all() and torch.equal(full[3::90], a)
+
+
+def test_glass_grid_depth_31_full_frame(torch, pt):
+    sc = pt.Scene(*pt.glass_grid_scene(5))
+    fast = sc.render(pt.make_config(W, H, SPP, n_bounces=31))
+    assert torch.isfinite(fast).all() and float(fast.min()) >= 0.0
+    par = sc.render(pt.make_config(W, H, SPP, n_bounces=31, math_mode=pt.PT_MATH_PARITY))
+    mf, mp = fast.double().mean(dim=(0, 1)), par.double().mean(dim=(0, 1))
+    assert float(((mf - mp).abs() / mp).max()) < 0.005       # measured 0.23-0.30 %: see the note on reflected rays
+    # deeper paths only add light
+    shallow = sc.render(pt.make_config(W, H, SPP, n_bounces=5))
+    assert float((fast.double().mean() - shallow.double().mean())) > 0.0

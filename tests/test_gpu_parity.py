@@ -24,19 +24,6 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.fixture(scope="module")
-def torch():
-    import torch
-    assert torch.cuda.is_available(), "these tests need an MI355X"
-    return torch
-
-
-@pytest.fixture(scope="module")
-def pt():
-    import pathtracer_amd
-    return pathtracer_amd
-
-
 def ulp_diff(a, b):
     """Distance in units in the last place between two float32 arrays (same sign assumed for non-zero values)."""
     ai = a.astype(np.float32).view(np.int32).astype(np.int64)
