@@ -51,7 +51,7 @@ typedef struct pt_prim {
 enum {
     PT_MATH_PARITY = 0, /* reference operation order, IEEE div/sqrt, no FMA contraction */
     PT_MATH_FAST = 1,   /* same algorithm, FMA + v_rcp/v_rsq/v_sin/v_cos, restructured tests; scenes with
-                         * 32 or more finite primitives are searched through a bounding-volume hierarchy
+                         * 96 or more finite primitives are searched through a bounding-volume hierarchy
                          * (same nearest hit as the loop of shapes.h:82-98, lowest index on ties) */
     /* The loop over ALL primitives, in its two forms (same results bit for bit): */
     PT_MATH_FAST_SCALAR = 2, /* primitive records fetched by scalar loads */

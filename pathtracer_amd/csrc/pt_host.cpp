@@ -420,7 +420,9 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
     const int n_chunks = pack_runs(baked, all, fdata, runs, chunk_runs);
     std::vector<BNode> bnodes;
     std::vector<BPrim> bprims;
-    if ((int)finite.size() >= BVH_MIN_PRIMS) {
+    int bvh_min = BVH_MIN_PRIMS;
+    if (const char* e = std::getenv("PT_BVH_MIN")) { const int v = std::atoi(e); if (v >= 2) bvh_min = v; }
+    if ((int)finite.size() >= bvh_min) {
         int leaf_prims = BVH_LEAF_PRIMS;
         if (const char* e = std::getenv("PT_BVH_LEAF")) { const int v = std::atoi(e); if (v >= 1 && v <= 15) leaf_prims = v; }
         build_bvh(baked, finite, 0, (int)finite.size(), bnodes, bprims, leaf_prims);

@@ -84,7 +84,8 @@ struct BPrim {
     int32_t id;
     int32_t pad[2];
 };
-constexpr int BVH_MIN_PRIMS = 32;    // fewer finite primitives than this: no hierarchy, the loop tests them all
+constexpr int BVH_MIN_PRIMS = 96;    // fewer finite primitives than this: no hierarchy, the loop tests them all (measured
+                                     // crossover: ~60 tiny scattered shapes, above 65 large glass spheres at depth 31)
 constexpr int BVH_LEAF_PRIMS = 1;     // measured on the 10 000-primitive scene: 1 is fastest (24.4 ms), 4: 27.7, 8: 29.5
 
 enum { FP_PLANE = 0, FP_CUBE = 1, FP_CYLINDER = 2, FP_SPHERE = 3, FP_SPHERE_WS = 4, FP_PLANE_GEN = 5 };

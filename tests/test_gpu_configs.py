@@ -128,10 +128,11 @@ def test_hierarchy_equals_loop_over_all_primitives_bitwise():
     import pathtracer_amd as pt
     small = pt.Scene(*pt.default_scene())
     assert small.bvh_nodes == 0                        # 4 finite primitives: no hierarchy
+    assert pt.Scene(*pt.glass_grid_scene(5)).bvh_nodes == 0   # 26: below the threshold, the loop is faster
     cases = ((pt.synthetic_scene(5000, 4989, 12345), (160, 90, 4, 5)), (pt.synthetic_scene(700, 300, 7), (130, 50, 3, 5)),
-             (pt.glass_grid_scene(6), (200, 120, 4, 31)),
+             (pt.glass_grid_scene(10), (200, 120, 4, 31)),
              (pt.parse_scene(_mixed_scene_text(120)), (192, 108, 8, 8)),
-             (pt.parse_scene(_mixed_scene_text(40, walls=False)), (96, 64, 8, 5)))
+             (pt.parse_scene(_mixed_scene_text(100, walls=False)), (96, 64, 8, 5)))
     for scene, (w, h, spp, depth) in cases:
         sc = pt.Scene(*scene)
         assert sc.bvh_nodes > 0
