@@ -365,13 +365,18 @@ struct Path {
 };
 
 // The tracePath loop body after the nearest hit is known (bsdf.h:84-165); true = continue.
-PTD bool path_shade(Path& p, const Best& b, const FShade* shade, const DMat* mats, int n_bounces, PhaseClock& clk) {
-    if (b.id < 0) return false;
+// Written with one exit and unconditional updates of the path: a lane whose path ends here (miss, roulette, depth) is
+// refilled before its state is read again, so its o, d, coef may hold anything, and the compiler need not keep the old
+// and the new state side by side (every early return used to cost a round of register copies per iteration).
+PTD bool path_shade(Path& p, const Best& b0, const FShade* shade, const DMat* mats, int n_bounces, PhaseClock& clk) {
+    const bool hit = b0.id >= 0;
+    Best b = b0;
+    b.id = hit ? b0.id : 0;                            // a miss reads primitive 0's records and is dropped at the end
     const Surf s = surface(b, p.o, p.d, shade);
     const DMat& M = mats[s.material];
     const V3 em = v3(M.emissive[0], M.emissive[1], M.emissive[2]);
     PHASE(clk, 2);
-    if ((max3(em.x, em.y, em.z) > 0.0f) || (min3(em.x, em.y, em.z) < 0.0f)) p.contrib = v3(__builtin_fmaf(em.x, p.coef.x, p.contrib.x), __builtin_fmaf(em.y, p.coef.y, p.contrib.y), __builtin_fmaf(em.z, p.coef.z, p.contrib.z));
+    if (hit && ((max3(em.x, em.y, em.z) > 0.0f) || (min3(em.x, em.y, em.z) < 0.0f))) p.contrib = v3(__builtin_fmaf(em.x, p.coef.x, p.contrib.x), __builtin_fmaf(em.y, p.coef.y, p.contrib.y), __builtin_fmaf(em.z, p.coef.z, p.contrib.z));
     const float f0 = M.f0, transparency = M.transparency;
     float p_specular = f0, p_refract = transparency;
     const bool glassy = (f0 > 0.0f) || (transparency > 0.0f);
@@ -430,15 +435,13 @@ PTD bool path_shade(Path& p, const Best& b, const FShade* shade, const DMat* mat
     const float q = max3(p.coef.x, p.coef.y, p.coef.z);
     // Russian roulette (bsdf.h:160-164): u in (0,1], so q >= 1 always survives
     // and q <= 0 never does; only 0 < q < 1 (or NaN) needs the draw.
-    if (q <= 0.0f) return false;
-    if (!(q >= 1.0f)) {
-        if (rng_u(p.key, slot + 5u) > q) return false;
-    }
+    bool dead = !hit || q <= 0.0f;
+    if (!(q >= 1.0f)) dead = dead || rng_u(p.key, slot + 5u) > q;
     p.coef = p.coef * rcp(q);
     p.o = s.pos;
     p.d = ndir;
     p.seg++;
-    return p.seg <= n_bounces;
+    return !dead && p.seg <= n_bounces;
 }
 
 // The loop body of bsdf_alternative.h:158-217 after the nearest hit is known: Lambertian or SmoothDielectric by
@@ -575,6 +578,8 @@ struct FastCtx {
 template <bool BVH>
 struct FastTracer {
     using Path = typename std::conditional<BVH, ptf::WalkPath, ptf::Path>::type;
+    // The hierarchy walk counts lanes (shade gate), so there only lanes with a path step.
+    static constexpr bool STEP_IDLE_LANES = !BVH;
     // Lane px prepares pixel px of the tile: jitter-free sample-plane coordinates
     // (main.cu:62) and the pixel's RNG key.
     static PTD void prologue(const RenderArgs& a, FastCtx& c, uint32_t px, const ptw::PixelRef& ref) {

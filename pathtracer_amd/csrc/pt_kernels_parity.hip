@@ -11,6 +11,8 @@ struct ParityCtx {};
 
 struct ParityTracer {
     using Path = ptp::Path;
+    static constexpr bool STEP_IDLE_LANES = false;
+    static __device__ __forceinline__ void idle(Path&) {}
     static __device__ __forceinline__ void prologue(const RenderArgs&, ParityCtx&, uint32_t, const ptw::PixelRef&) {}
     static __device__ __forceinline__ void start(Path& p, const RenderArgs& a, ParityCtx&, uint32_t, uint32_t lin, uint32_t sample) {
         const ptw::PixelRef ref = ptw::pixel_of(a, lin);

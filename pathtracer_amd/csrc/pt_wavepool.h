@@ -89,6 +89,8 @@ __device__ __forceinline__ void store_tile(const RenderArgs& a, const WaveLds& l
 //              static bool step(Path&, const RenderArgs&, Ctx&);     // true = path continues
 //              static void radiance(const Path&, float rgb[3]);
 //              static void phase(Ctx&, int);                          // development profiling hook, normally empty
+//              static constexpr bool STEP_IDLE_LANES;                 // step() may run for lanes without a path
+//              static void idle(Path&);                               // a state step() can run on harmlessly
 template <class T, class Ctx>
 __device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, WaveLds& l, Ctx& ctx) {
     const unsigned lane = lane_id();
@@ -106,6 +108,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, 
     // One wave touches this LDS slice, in program order: no barrier needed.
 
     typename T::Path path;
+    if (T::STEP_IDLE_LANES) T::idle(path);
     uint32_t my_px = 0;
     bool active = false;
     uint32_t next = 0;   // wave-uniform
@@ -128,7 +131,19 @@ __device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, 
             if (next >= total) break;
             continue;
         }
-        if (active) {
+        if (T::STEP_IDLE_LANES) {
+            // Lanes without a path step whatever state they hold (a finished path or the idle ray) and the result is
+            // dropped: the wave spends the same time, and the path state has one definition per iteration instead of a
+            // merge of "stepped" and "left alone" that costs a round of register copies.
+            const bool go_on = T::step(path, a, ctx);
+            T::phase(ctx, 5);
+            if (active && !go_on) {
+                float rgb[3];
+                T::radiance(path, rgb);
+                add_sample(l, my_px, rgb);
+                active = false;
+            }
+        } else if (active) {
             const bool go_on = T::step(path, a, ctx);
             T::phase(ctx, 5);
             if (!go_on) {
