@@ -323,12 +323,15 @@ struct Path {
 // One iteration of the tracePath loop (bsdf.h:78-166).  Returns true when the
 // path goes on to another segment.  Draw slots of segment s are 2+6s+{0..5};
 // draws whose value cannot change the result are not evaluated.
+// One exit and unconditional updates of o, d, coef: a lane whose path ends here is refilled before that state is read
+// again, so it may hold anything, and the old and new state never have to coexist in registers.  A miss goes through
+// the arithmetic with primitive 0's material and is dropped at the end; the arithmetic of a live path is untouched.
 PTD bool path_step(Path& p, const DPrim* __restrict__ prims, int n_prims, const DMat* __restrict__ mats, int n_bounces) {
     Hit h = nearest_hit(p.o, p.d, prims, n_prims);
-    if (h.prim < 0) return false;
-    const DMat& M = mats[prims[h.prim].material];
+    const bool hit = h.prim >= 0;
+    const DMat& M = mats[prims[hit ? h.prim : 0].material];
     V3 emissive = v3(M.emissive[0], M.emissive[1], M.emissive[2]);
-    if (sqn(emissive) > 0.0f) p.contrib = p.contrib + emissive * p.coef;
+    if (hit && sqn(emissive) > 0.0f) p.contrib = p.contrib + emissive * p.coef;
     if (p.seg > 0 && h.inside) {
         V3 rc = v3(M.refractionColor[0], M.refractionColor[1], M.refractionColor[2]);
         V3 att = (-1.0f * rc) * h.t;
@@ -375,12 +378,12 @@ PTD bool path_step(Path& p, const DPrim* __restrict__ prims, int n_prims, const 
     else if (mode == 3) p.coef = p.coef * v3(M.albedo[0], M.albedo[1], M.albedo[2]);
     p.coef = p.coef / p_ray;
     float q = fmaxf(p.coef.x, fmaxf(p.coef.y, p.coef.z));
-    if (rng_u(p.key, slot + 5u) > q) return false;
+    const bool dead = !hit || rng_u(p.key, slot + 5u) > q;
     p.coef = (p.coef * 1.0f) / q;
     p.o = h.pos;
     p.d = ndir;
     p.seg++;
-    return p.seg <= n_bounces;
+    return !dead && p.seg <= n_bounces;
 }
 
 // ---- bsdf_alternative.h: the class-based BSDFs and their tracePath -------------------------
