@@ -1,0 +1,195 @@
+"""The oracle against geometry worked out independently in float64 numpy (not against vectors the oracle itself
+produced): random affine transforms, random rays, closed-form intersections of the unit shapes of shapes.h:102,136,224,322.
+Rays within a margin of a decision threshold (tangent, on an edge, at the epsilon) are left out: there float32 and
+float64 may legitimately disagree."""
+import numpy as np
+import pytest
+
+EPS = 1e-5
+N = 6000
+
+
+def _rotation(rng):
+    ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+    a = rng.uniform(0, 2 * np.pi)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * (K @ K)
+
+
+def _transform(rng, uniform=False):
+    s = np.full(3, rng.uniform(0.3, 2.0)) if uniform else rng.uniform(0.3, 2.0, 3)
+    L = _rotation(rng) @ np.diag(s)
+    t = rng.uniform(-2, 2, 3) + np.array([0, 0, -4.0])
+    return L.astype(np.float32).astype(np.float64), t.astype(np.float32).astype(np.float64)   # what the oracle is given
+
+
+def _rays(rng, L, t, n):
+    """Rays from around the camera volume aimed at points in and closely around the unit shape under [L | t]; a
+    twentieth of them start inside it."""
+    o = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    o[: n // 20] = (t + rng.uniform(-0.2, 0.2, (n // 20, 3)) @ L.T).astype(np.float32)
+    target = t + rng.uniform(-0.8, 0.8, (n, 3)) @ L.T
+    d = target - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    return o, d
+
+
+def _local(L, t, o, d):
+    Li = np.linalg.inv(L)
+    return (o.astype(np.float64) - t) @ Li.T, d.astype(np.float64) @ Li.T
+
+
+def _prim(ob, ptype, L, t, bounds=None):
+    T = np.concatenate([L, t[:, None]], axis=1).astype(np.float32).ravel()
+    return ob.make_prim(ptype, transform=list(T), bounds=bounds)
+
+
+def _close(a, b, rel=2e-4):
+    return np.abs(a - b) <= rel * (1.0 + np.abs(b))
+
+
+def _check_pair(r, te, tx, generic, what):
+    """Oracle result r against entry/exit distances te < tx of a convex solid, for rays marked generic."""
+    out = generic & (te > 10 * EPS)                 # origin outside, solid ahead: two hits
+    assert out.sum() > 200, what
+    assert np.array_equal(r["n"][out], np.full(out.sum(), 2)), what
+    lo = np.minimum(r["t1"], r["t2"]); hi = np.maximum(r["t1"], r["t2"])
+    assert _close(lo[out], te[out]).all() and _close(hi[out], tx[out]).all(), what
+    inside = generic & (te < -10 * EPS) & (tx > 10 * EPS)      # origin inside: the entry is dropped by the epsilon filter
+    if inside.sum():
+        assert np.array_equal(r["n"][inside], np.full(inside.sum(), 1)), what
+        assert _close(r["t1"][inside], tx[inside]).all(), what
+    behind = generic & (tx < -10 * EPS)
+    if behind.sum():
+        assert (r["n"][behind] == 0).all(), what
+
+
+def test_sphere_against_closed_form(oracle):
+    ob = oracle
+    rng = np.random.default_rng(101)
+    for trial in range(4):
+        L, t = _transform(rng, uniform=(trial % 2 == 0))
+        o, d = _rays(rng, L, t, N)
+        r = ob.raypath(_prim(ob, ob.SPHERE, L, t), o, d)
+        ol, dl = _local(L, t, o, d)
+        a = (dl * dl).sum(1); b = 2 * (dl * ol).sum(1); c = (ol * ol).sum(1) - 0.25
+        disc = b * b - 4 * a * c
+        miss = disc < -1e-3 * b * b
+        assert (r["n"][miss] == 0).all()
+        hit = disc > 1e-3 * b * b
+        sq = np.sqrt(np.where(hit, disc, 0.0))
+        te, tx = (-b - sq) / (2 * a), (-b + sq) / (2 * a)
+        _check_pair(r, te, tx, hit, "sphere")
+        # the reported position is o + d t, on the surface; the normal is unit, and radial when the scale is uniform
+        two = hit & (te > 10 * EPS)
+        pos = r["pos1"][two].astype(np.float64)
+        assert _close(pos, o[two] + d[two] * r["t1"][two, None], 1e-4).all()
+        pl = (pos - t) @ np.linalg.inv(L).T
+        assert np.abs(np.linalg.norm(pl, axis=1) - 0.5).max() < 2e-4
+        nrm = r["nrm1"][two].astype(np.float64)
+        assert np.abs(np.linalg.norm(nrm, axis=1) - 1).max() < 1e-5
+        if trial % 2 == 0:
+            radial = (pos - t) / np.linalg.norm(pos - t, axis=1, keepdims=True)
+            assert np.abs(nrm - radial).max() < 5e-4
+
+
+def test_plane_against_closed_form(oracle):
+    ob = oracle
+    rng = np.random.default_rng(102)
+    for trial in range(4):
+        L, t = _transform(rng)
+        bounds = (-0.8, -0.5, 0.6, 0.9)
+        o, d = _rays(rng, L, t, N)
+        r = ob.raypath(_prim(ob, ob.PLANE, L, t, bounds=bounds), o, d)
+        ol, dl = _local(L, t, o, d)
+        ok = np.abs(dl[:, 2]) > 1e-3
+        tt = -ol[:, 2] / np.where(ok, dl[:, 2], 1.0)
+        p = ol + dl * tt[:, None]
+        m = 1e-3
+        inside = (p[:, 0] > bounds[0] + m) & (p[:, 1] > bounds[1] + m) & (p[:, 0] < bounds[2] - m) & (p[:, 1] < bounds[3] - m)
+        outside = (p[:, 0] < bounds[0] - m) | (p[:, 1] < bounds[1] - m) | (p[:, 0] > bounds[2] + m) | (p[:, 1] > bounds[3] + m)
+        hit = ok & inside & (tt > 10 * EPS)
+        assert hit.sum() > 200
+        assert (r["n"][hit] == 1).all() and _close(r["t1"][hit], tt[hit]).all()
+        assert (r["n"][ok & outside] == 0).all()
+        assert (r["n"][ok & inside & (tt < -10 * EPS)] == 0).all()
+        # the normal is the plane's unit normal turned against the ray
+        nw = L[:, 2] / np.linalg.norm(L[:, 2])          # T*(0,0,1) - wOrigin
+        nrm = r["nrm1"][hit].astype(np.float64)
+        facing = np.where((dl[hit, 2] > 0)[:, None], -nw, nw)
+        assert np.abs(nrm - facing).max() < 1e-5
+        assert ((nrm * d[hit]).sum(1) < 0).all()
+
+
+def test_cube_against_closed_form(oracle):
+    ob = oracle
+    rng = np.random.default_rng(103)
+    for trial in range(4):
+        L, t = _transform(rng)
+        o, d = _rays(rng, L, t, N)
+        r = ob.raypath(_prim(ob, ob.CUBE, L, t), o, d)
+        ol, dl = _local(L, t, o, d)
+        ok = (np.abs(dl) > 1e-3).all(1)
+        inv = 1.0 / np.where(np.abs(dl) > 1e-3, dl, 1.0)
+        t0, t1 = (-0.5 - ol) * inv, (0.5 - ol) * inv
+        tmin = np.minimum(t0, t1).max(1); tmax = np.maximum(t0, t1).min(1)
+        gap = tmax - tmin
+        miss = ok & (gap < -1e-3)
+        assert (r["n"][miss] == 0).all()
+        _check_pair(r, tmin, tmax, ok & (gap > 1e-3), "cube")
+        # normals are unit and along a transformed axis
+        two = ok & (gap > 1e-3) & (tmin > 10 * EPS)
+        nrm = r["nrm1"][two].astype(np.float64)
+        axes = L / np.linalg.norm(L, axis=0, keepdims=True)
+        assert (np.abs(nrm @ axes).max(axis=1) > 1 - 1e-5).all()
+
+
+def test_cylinder_against_closed_form(oracle):
+    ob = oracle
+    rng = np.random.default_rng(104)
+    for trial in range(4):
+        L, t = _transform(rng)
+        o, d = _rays(rng, L, t, N)
+        r = ob.raypath(_prim(ob, ob.CYLINDER, L, t), o, d)
+        ol, dl = _local(L, t, o, d)
+        # solid = {x^2 + y^2 <= 0.25} intersected with {|z| <= 0.5}: interval arithmetic along the ray
+        a = dl[:, 0] ** 2 + dl[:, 1] ** 2; b = 2 * (dl[:, 0] * ol[:, 0] + dl[:, 1] * ol[:, 1]); c = ol[:, 0] ** 2 + ol[:, 1] ** 2 - 0.25
+        disc = b * b - 4 * a * c
+        ok = (a > 1e-3) & (np.abs(dl[:, 2]) > 1e-3) & (np.abs(disc) > 1e-3 * b * b)
+        sq = np.sqrt(np.where(disc > 0, disc, 0.0))
+        s0, s1 = (-b - sq) / (2 * np.where(ok, a, 1.0)), (-b + sq) / (2 * np.where(ok, a, 1.0))
+        iz = 1.0 / np.where(ok, dl[:, 2], 1.0)
+        z0, z1 = np.minimum((-0.5 - ol[:, 2]) * iz, (0.5 - ol[:, 2]) * iz), np.maximum((-0.5 - ol[:, 2]) * iz, (0.5 - ol[:, 2]) * iz)
+        te, tx = np.maximum(s0, z0), np.minimum(s1, z1)
+        gap = np.where(disc > 0, tx - te, -1.0)
+        miss = ok & (gap < -1e-3)
+        # a ray that misses the solid may still report the reference's case-2/3 pairing of a disc with an out-of-range
+        # side root only when it hits a cap disc, which a miss of the solid excludes
+        assert (r["n"][miss] == 0).all()
+        # keep away from the rims, where a cap hit and a side hit trade places
+        rim = (np.abs(np.abs(ol[:, 2] + dl[:, 2] * te) - 0.5) < 1e-3) & (np.abs((ol[:, 0] + dl[:, 0] * te) ** 2 + (ol[:, 1] + dl[:, 1] * te) ** 2 - 0.25) < 1e-3)
+        rim |= (np.abs(np.abs(ol[:, 2] + dl[:, 2] * tx) - 0.5) < 1e-3) & (np.abs((ol[:, 0] + dl[:, 0] * tx) ** 2 + (ol[:, 1] + dl[:, 1] * tx) ** 2 - 0.25) < 1e-3)
+        _check_pair(r, te, tx, ok & (gap > 1e-3) & ~rim, "cylinder")
+
+
+def test_nearest_is_the_minimum_over_shapes(oracle):
+    """getNearestIntersection (shapes.h:79-100) on the default scene against the per-shape results."""
+    ob = oracle
+    prims, n, mats, nm = ob.default_scene()
+    sc = ob.Scene(prims, n, mats, nm)
+    rng = np.random.default_rng(105)
+    o = rng.uniform([-0.9, -0.9, -4.5], [0.9, 0.9, 0.0], (4000, 3)).astype(np.float32)
+    d = rng.normal(size=(4000, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    near = sc.nearest(o, d)
+    best_t = np.full(4000, np.inf); best_k = np.full(4000, -1)
+    for k in range(n):
+        r = ob.raypath(prims[k], o, d)
+        t = np.where(r["n"] == 2, np.minimum(r["t1"], r["t2"]), r["t1"]).astype(np.float64)
+        valid = (r["n"] >= 1) & np.where((r["n"] == 2) & (r["t2"] < r["t1"]), r["hit2"], r["hit1"]).astype(bool)
+        better = valid & (t < best_t)
+        best_t[better] = t[better]; best_k[better] = k
+    assert np.array_equal(near["prim"], best_k)
+    assert np.array_equal(near["t"][best_k >= 0], best_t[best_k >= 0].astype(np.float32))
+    # facing normal and inside flag: inside means the geometric normal pointed along the ray
+    hit = best_k >= 0
+    assert ((near["nrm"][hit].astype(np.float64) * d[hit]).sum(1) <= 1e-6).all()
