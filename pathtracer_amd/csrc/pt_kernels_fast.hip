@@ -600,6 +600,25 @@ struct FastTracer {
         p.seg = 0;
         begin_search(p);
     }
+    // The same in two halves for the ray stash: what depends on the pool item, and what sets up the lane's path.
+    static PTD void make_ray(const RenderArgs& a, FastCtx& c, uint32_t px, uint32_t sample, float4& ray) {
+        const uint32_t kpx = __float_as_uint(c.pxt[128 + px]);
+        const uint32_t key = rng_hash(kpx + 0x9E3779B9u * (sample + 1u));
+        const float sx = c.pxt[px] + rng_u(key, 0u), sy = c.pxt[64 + px] + rng_u(key, 1u);
+        const V3 cam = v3(a.cam[0], a.cam[1], a.cam[2]);
+        const V3 pc = v3(__builtin_fmaf(a.du, sx, a.p00[0]), __builtin_fmaf(a.dv, sy, a.p00[1]), a.p00[2]);
+        const V3 d = unit(pc - cam);
+        ray = make_float4(d.x, d.y, d.z, __uint_as_float(key));
+    }
+    static PTD void begin(Path& p, const RenderArgs& a, FastCtx&, const float4& ray) {
+        p.key = __float_as_uint(ray.w);
+        p.o = v3(a.cam[0], a.cam[1], a.cam[2]);
+        p.d = v3(ray.x, ray.y, ray.z);
+        p.coef = v3(1.0f, 1.0f, 1.0f);
+        p.contrib = v3(0.0f, 0.0f, 0.0f);
+        p.seg = 0;
+        begin_search(p);
+    }
     static PTD void begin_search(ptf::Path&) {}
     static PTD void begin_search(ptf::WalkPath& p) { p.node = -1; }
     static PTD bool step(Path& p, const RenderArgs& a, FastCtx& c) {
@@ -647,6 +666,7 @@ template <bool LDS_TABLES, bool BVH>
 __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, uint32_t n_tiles) {
     __shared__ ptw::WaveLds lds[ptw::WAVES_PER_BLOCK];
     __shared__ float pxt[ptw::WAVES_PER_BLOCK][192];
+    __shared__ float4 stash[BVH ? 1 : ptw::WAVES_PER_BLOCK][BVH ? 1 : 64];
     __shared__ FShade lshade[LDS_TABLES ? LDS_MAX_PRIMS : 1];
     __shared__ DMat lmats[LDS_TABLES ? LDS_MAX_MATS : 1];
     FastCtx ctx;
@@ -668,7 +688,8 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, u
     if (tile >= n_tiles) return;
     ctx.pxt = pxt[wave];
     ctx.clk.start();
-    ptw::render_tile<FastTracer<BVH>>(a, tile, lds[wave], ctx);
+    if (BVH) ptw::render_tile<FastTracer<BVH>>(a, tile, lds[wave], ctx);
+    else ptw::render_tile_stash<FastTracer<BVH>>(a, tile, lds[wave], stash[BVH ? 0 : wave], ctx);
     ctx.clk.flush(threadIdx.x & 63);
 }
 

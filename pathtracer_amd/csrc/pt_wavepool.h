@@ -158,6 +158,79 @@ __device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, 
     store_tile(a, l, npx, lane);
 }
 
+// render_tile with the camera rays made 64 at a time.  Handing out work inside render_tile runs T::start for the
+// lanes whose path just ended, about 27 of 64 per iteration, at the price of a full wave.  Here all 64 lanes make the
+// rays of the next 64 pool items at once and park them in `stash` (LDS, one float4 per item: direction and RNG key);
+// a lane that needs work takes the next parked ray.  Items are still handed out in pool order, lane by lane, so the
+// assignment of samples to lanes is the one render_tile makes.
+// T additionally supplies:  static void make_ray(const RenderArgs&, Ctx&, uint32_t px, uint32_t sample, float4& ray);
+//                           static void begin(Path&, const RenderArgs&, Ctx&, const float4& ray);
+template <class T, class Ctx>
+__device__ __forceinline__ void render_tile_stash(const RenderArgs& a, uint32_t tile, WaveLds& l, float4* stash, Ctx& ctx) {
+    const unsigned lane = lane_id();
+    const uint32_t lg = (uint32_t)a.tile_log2, P = 1u << lg;
+    const uint32_t lin_base = tile << lg;
+    const uint32_t npx = min(P, a.n_lin - lin_base);
+    const uint32_t total = (uint32_t)a.n_samples << lg;
+
+    l.acc[lane] = 0ull; l.acc[lane + 64] = 0ull; l.acc[lane + 128] = 0ull;
+    if (lane < npx) {
+        const PixelRef ref = pixel_of(a, lin_base + lane);
+        l.out_px[lane] = ref.out;
+        T::prologue(a, ctx, lane, ref);
+    }
+
+    typename T::Path path;
+    T::idle(path);
+    uint32_t my_px = 0;
+    bool active = false;
+    uint32_t made = 0, taken = 0;   // wave-uniform: pool items whose ray has been made / handed out; parked = made - taken
+    for (;;) {
+        const unsigned long long want = __ballot(!active);
+        uint32_t need = (uint32_t)__popcll(want);
+        if (need != 0u) {
+            const uint32_t rank = prefix_count(want);
+            uint32_t served = 0;
+            for (int pass = 0; pass < 2 && need != 0u; pass++) {   // what is parked, then a fresh batch for the rest
+                if (made == taken) {
+                    if (made >= total) break;
+                    const uint32_t w = made + lane;
+                    float4 ray;
+                    T::make_ray(a, ctx, w & (P - 1u), w >> lg, ray);
+                    stash[w & 63u] = ray;
+                    made = min(made + 64u, total);
+                }
+                const uint32_t take = min(need, made - taken);
+                if (!active && rank >= served && rank < served + take) {
+                    const uint32_t item = taken + (rank - served);
+                    const uint32_t px = item & (P - 1u);
+                    if (px < npx) {
+                        my_px = px;
+                        T::begin(path, a, ctx, stash[item & 63u]);
+                        active = true;
+                    }
+                }
+                taken += take; served += take; need -= take;
+            }
+        }
+        T::phase(ctx, 0);
+        if (__ballot(active) == 0ull) {
+            if (taken >= total) break;
+            continue;
+        }
+        const bool go_on = T::step(path, a, ctx);      // idle lanes step too, see render_tile
+        T::phase(ctx, 5);
+        if (active && !go_on) {
+            float rgb[3];
+            T::radiance(path, rgb);
+            add_sample(l, my_px, rgb);
+            active = false;
+        }
+        T::phase(ctx, 6);
+    }
+    store_tile(a, l, npx, lane);
+}
+
 // The same pool, for tracers whose nearest-hit search is a WORKGROUP-wide operation (records staged through LDS
 // with barriers inside): every wave of the block calls this, also one whose tile lies beyond the image, and all
 // of them keep taking part in the search until the last wave of the block has drained its pool.
