@@ -154,3 +154,38 @@ def test_hierarchy_equals_loop_over_all_primitives_bitwise():
     par = sc.trace_paths(*args, seed=0, n_bounces=0, math_mode=pt.PT_MATH_PARITY).cpu().numpy()
     # one segment: the radiance is the emission of whatever the ray hits first
     assert (np.abs(fast - par).max(axis=1) > 1e-3).mean() < 0.002
+
+
+def test_more_materials_and_primitives_than_the_lds_tables_hold(oracle):
+    """Above 32 materials (or 64 primitives) the fast kernels gather shading records and materials from global memory
+    instead of their LDS copies: same arithmetic, so the LDS-staged loop still matches bit for bit, and the parity-order
+    kernel still matches the oracle."""
+    import torch
+    import pathtracer_amd as pt
+    rng = np.random.default_rng(9)
+    lines = ["material light emissive 20 18 14"]
+    for m in range(40):
+        c = rng.uniform(0.1, 0.9, 3)
+        lines.append("material m%d albedo %.3f %.3f %.3f" % (m, c[0], c[1], c[2]))
+    lines += ["plane m0 bounds -15 -15 15 15 rotate pi/2 1 0 0 translate 0 -1 0",
+              "plane m1 bounds -15 -15 15 15 translate 0 0 -5",
+              "plane light bounds -0.5 -0.5 0.5 0.5 rotate -pi/2 1 0 0 translate 0 0.97 -3.25"]
+    for k in range(70):
+        pos = rng.uniform([-0.9, -0.9, -4.8], [0.9, 0.9, -1.6])
+        lines.append("%s m%d translate %.4f %.4f %.4f scale %.4f" % (("sphere", "cube")[k % 2], k % 40, pos[0], pos[1], pos[2], rng.uniform(0.05, 0.2)))
+    prims, n, mats, nm = pt.parse_scene("\n".join(lines) + "\n")
+    assert nm == 41 and n == 73
+    sc = pt.Scene(prims, n, mats, nm)
+    assert sc.bvh_nodes == 0                       # 70 finite primitives: below the hierarchy's threshold
+    w, h, spp = 160, 90, 8
+    a = sc.render(pt.make_config(w, h, spp, math_mode=pt.PT_MATH_FAST))
+    b = sc.render(pt.make_config(w, h, spp, math_mode=pt.PT_MATH_FAST_LDS))
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    osc = oracle.Scene(*_as_oracle(oracle, prims, n, mats, nm))
+    ref = osc.render(oracle.make_config(w, h, spp))
+    par = sc.render(pt.make_config(w, h, spp, math_mode=pt.PT_MATH_PARITY)).cpu().numpy()
+    rp, bp = _stats(par, ref)
+    rf, bf = _stats(a.cpu().numpy(), ref)
+    print("41 materials / 73 primitives: parity rmse %.2e bad %.5f | fast rmse %.2e bad %.5f" % (rp, bp, rf, bf))
+    assert rp <= 0.01 and bp <= 0.001
+    assert bf <= 0.02
