@@ -601,7 +601,7 @@ struct FastTracer {
         begin_search(p);
     }
     // The same in two halves for the ray stash: what depends on the pool item, and what sets up the lane's path.
-    static PTD void make_ray(const RenderArgs& a, FastCtx& c, uint32_t px, uint32_t sample, float4& ray) {
+    static PTD void make_ray(const RenderArgs& a, FastCtx& c, uint32_t px, uint32_t, uint32_t sample, float4& ray) {
         const uint32_t kpx = __float_as_uint(c.pxt[128 + px]);
         const uint32_t key = rng_hash(kpx + 0x9E3779B9u * (sample + 1u));
         const float sx = c.pxt[px] + rng_u(key, 0u), sy = c.pxt[64 + px] + rng_u(key, 1u);

@@ -11,8 +11,27 @@ struct ParityCtx {};
 
 struct ParityTracer {
     using Path = ptp::Path;
-    static constexpr bool STEP_IDLE_LANES = false;
-    static __device__ __forceinline__ void idle(Path&) {}
+    static __device__ __forceinline__ void idle(Path& p) {
+        p.o = v3(0.0f, 0.0f, 0.0f); p.d = v3(0.0f, 0.0f, 0.0f);
+        p.coef = v3(0.0f, 0.0f, 0.0f); p.contrib = v3(0.0f, 0.0f, 0.0f); p.key = 0; p.seg = 0;
+    }
+    // start() in two halves for the ray stash; a pool item past the launch's last pixel (ragged tile) makes a ray that
+    // is never begun, so its pixel is clamped into the launch.
+    static __device__ __forceinline__ void make_ray(const RenderArgs& a, ParityCtx&, uint32_t, uint32_t lin, uint32_t sample, float4& ray) {
+        const ptw::PixelRef ref = ptw::pixel_of(a, lin < a.n_lin ? lin : 0u);
+        const uint32_t key = rng_key(a.seed_hash, ref.index, sample);
+        V3 o, d;
+        camera_ray(a, ref.i, ref.j, key, &o, &d);
+        ray = make_float4(d.x, d.y, d.z, __uint_as_float(key));
+    }
+    static __device__ __forceinline__ void begin(Path& p, const RenderArgs& a, ParityCtx&, const float4& ray) {
+        p.key = __float_as_uint(ray.w);
+        p.o = v3(a.cam[0], a.cam[1], a.cam[2]);
+        p.d = v3(ray.x, ray.y, ray.z);
+        p.coef = v3(1.0f, 1.0f, 1.0f);
+        p.contrib = v3(0.0f, 0.0f, 0.0f);
+        p.seg = 0;
+    }
     static __device__ __forceinline__ void prologue(const RenderArgs&, ParityCtx&, uint32_t, const ptw::PixelRef&) {}
     static __device__ __forceinline__ void start(Path& p, const RenderArgs& a, ParityCtx&, uint32_t, uint32_t lin, uint32_t sample) {
         const ptw::PixelRef ref = ptw::pixel_of(a, lin);
@@ -34,11 +53,12 @@ struct ParityTracer {
 
 __global__ __launch_bounds__(ptw::BLOCK) void render_parity_kernel(RenderArgs a, uint32_t n_tiles) {
     __shared__ ptw::WaveLds lds[ptw::WAVES_PER_BLOCK];
+    __shared__ float4 stash[ptw::WAVES_PER_BLOCK][64];
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t tile = blockIdx.x * ptw::WAVES_PER_BLOCK + wave;
     if (tile >= n_tiles) return;
     ParityCtx ctx;
-    ptw::render_tile<ParityTracer>(a, tile, lds[wave], ctx);
+    ptw::render_tile_stash<ParityTracer>(a, tile, lds[wave], stash[wave], ctx);
 }
 
 __device__ __forceinline__ V3 load3(const float* p, int i) { return v3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }

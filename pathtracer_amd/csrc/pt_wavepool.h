@@ -196,7 +196,7 @@ __device__ __forceinline__ void render_tile_stash(const RenderArgs& a, uint32_t 
                     if (made >= total) break;
                     const uint32_t w = made + lane;
                     float4 ray;
-                    T::make_ray(a, ctx, w & (P - 1u), w >> lg, ray);
+                    T::make_ray(a, ctx, w & (P - 1u), lin_base + (w & (P - 1u)), w >> lg, ray);
                     stash[w & 63u] = ray;
                     made = min(made + 64u, total);
                 }
