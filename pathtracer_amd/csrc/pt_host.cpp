@@ -531,8 +531,9 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     // fixed-point sums).
     a.tile_log2 = a.n_lin >= 6000000u ? 6 : (a.n_lin >= 1500000u ? 5 : (a.n_lin >= 200000u ? 4 : 3));
     // ... and a pool of at least ~2048 samples per wave, or the drain phase dominates at low sample counts (10 000
-    // primitives, 1080p, 4 spp: 263 ms with 32 pixels per wave, 216 ms with 64).
-    while (a.tile_log2 < 6 && ((uint32_t)cfg->n_samples << a.tile_log2) < 2048u) a.tile_log2++;
+    // primitives, 1080p, 4 spp: 263 ms with 32 pixels per wave, 216 ms with 64) — as long as that leaves two waves
+    // for every wave slot of the chip.
+    while (a.tile_log2 < 6 && ((uint32_t)cfg->n_samples << a.tile_log2) < 2048u && (a.n_lin >> (a.tile_log2 + 1)) >= 16384u) a.tile_log2++;
     if (const char* e = std::getenv("PT_TILE_LOG2")) { const int v = std::atoi(e); if (v >= 2 && v <= 6) a.tile_log2 = v; }
     a.fb_layout = cfg->fb_layout;
     a.n_prims = sc->n_prims; a.n_mats = sc->n_mats;

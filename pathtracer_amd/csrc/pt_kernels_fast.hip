@@ -666,7 +666,7 @@ template <bool LDS_TABLES, bool BVH>
 __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, uint32_t n_tiles) {
     __shared__ ptw::WaveLds lds[ptw::WAVES_PER_BLOCK];
     __shared__ float pxt[ptw::WAVES_PER_BLOCK][192];
-    __shared__ float4 stash[BVH ? 1 : ptw::WAVES_PER_BLOCK][BVH ? 1 : 64];
+    __shared__ float4 stash[ptw::WAVES_PER_BLOCK][64];
     __shared__ FShade lshade[LDS_TABLES ? LDS_MAX_PRIMS : 1];
     __shared__ DMat lmats[LDS_TABLES ? LDS_MAX_MATS : 1];
     FastCtx ctx;
@@ -688,8 +688,7 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, u
     if (tile >= n_tiles) return;
     ctx.pxt = pxt[wave];
     ctx.clk.start();
-    if (BVH) ptw::render_tile<FastTracer<BVH>>(a, tile, lds[wave], ctx);
-    else ptw::render_tile_stash<FastTracer<BVH>>(a, tile, lds[wave], stash[BVH ? 0 : wave], ctx);
+    ptw::render_tile<FastTracer<BVH>>(a, tile, lds[wave], stash[wave], ctx);
     ctx.clk.flush(threadIdx.x & 63);
 }
 

@@ -11,11 +11,12 @@ struct ParityCtx {};
 
 struct ParityTracer {
     using Path = ptp::Path;
+    static constexpr bool STEP_IDLE_LANES = true;
     static __device__ __forceinline__ void idle(Path& p) {
         p.o = v3(0.0f, 0.0f, 0.0f); p.d = v3(0.0f, 0.0f, 0.0f);
         p.coef = v3(0.0f, 0.0f, 0.0f); p.contrib = v3(0.0f, 0.0f, 0.0f); p.key = 0; p.seg = 0;
     }
-    // start() in two halves for the ray stash; a pool item past the launch's last pixel (ragged tile) makes a ray that
+    // A pool item past the launch's last pixel (ragged tile) makes a ray that
     // is never begun, so its pixel is clamped into the launch.
     static __device__ __forceinline__ void make_ray(const RenderArgs& a, ParityCtx&, uint32_t, uint32_t lin, uint32_t sample, float4& ray) {
         const ptw::PixelRef ref = ptw::pixel_of(a, lin < a.n_lin ? lin : 0u);
@@ -33,14 +34,6 @@ struct ParityTracer {
         p.seg = 0;
     }
     static __device__ __forceinline__ void prologue(const RenderArgs&, ParityCtx&, uint32_t, const ptw::PixelRef&) {}
-    static __device__ __forceinline__ void start(Path& p, const RenderArgs& a, ParityCtx&, uint32_t, uint32_t lin, uint32_t sample) {
-        const ptw::PixelRef ref = ptw::pixel_of(a, lin);
-        p.key = rng_key(a.seed_hash, ref.index, sample);
-        camera_ray(a, ref.i, ref.j, p.key, &p.o, &p.d);
-        p.coef = v3(1.0f, 1.0f, 1.0f);
-        p.contrib = v3(0.0f, 0.0f, 0.0f);
-        p.seg = 0;
-    }
     static __device__ __forceinline__ bool step(Path& p, const RenderArgs& a, ParityCtx&) {
         if (a.bsdf_model == PT_BSDF_CLASSES) return path_step_alt(p, a.prims, a.n_prims, a.mats, a.n_bounces);
         return path_step(p, a.prims, a.n_prims, a.mats, a.n_bounces);
@@ -58,7 +51,7 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_parity_kernel(RenderArgs a,
     const uint32_t tile = blockIdx.x * ptw::WAVES_PER_BLOCK + wave;
     if (tile >= n_tiles) return;
     ParityCtx ctx;
-    ptw::render_tile_stash<ParityTracer>(a, tile, lds[wave], stash[wave], ctx);
+    ptw::render_tile<ParityTracer>(a, tile, lds[wave], stash[wave], ctx);
 }
 
 __device__ __forceinline__ V3 load3(const float* p, int i) { return v3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }

@@ -85,88 +85,20 @@ __device__ __forceinline__ void store_tile(const RenderArgs& a, const WaveLds& l
 
 // T supplies:  struct Path;
 //              static void prologue(const RenderArgs&, Ctx&, uint32_t px, const PixelRef&);   // per tile pixel, by lane px
-//              static void start(Path&, const RenderArgs&, Ctx&, uint32_t px, uint32_t lin, uint32_t sample);
+//              static void make_ray(const RenderArgs&, Ctx&, uint32_t px, uint32_t lin, uint32_t sample, float4& ray);
+//              static void begin(Path&, const RenderArgs&, Ctx&, const float4& ray);
 //              static bool step(Path&, const RenderArgs&, Ctx&);     // true = path continues
 //              static void radiance(const Path&, float rgb[3]);
 //              static void phase(Ctx&, int);                          // development profiling hook, normally empty
 //              static constexpr bool STEP_IDLE_LANES;                 // step() may run for lanes without a path
 //              static void idle(Path&);                               // a state step() can run on harmlessly
+//
+// Handing out work lane by lane would run the camera-ray code for the lanes whose path just ended, about 27 of 64 per
+// iteration, at the price of a full wave.  Instead all 64 lanes make the rays of the next 64 pool items at once and park
+// them in `stash` (LDS, one float4 per item: direction and RNG key); a lane that needs work takes the next parked ray.
+// Items are handed out in pool order, lane by lane.
 template <class T, class Ctx>
-__device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, WaveLds& l, Ctx& ctx) {
-    const unsigned lane = lane_id();
-    const uint32_t lg = (uint32_t)a.tile_log2, P = 1u << lg;
-    const uint32_t lin_base = tile << lg;
-    const uint32_t npx = min(P, a.n_lin - lin_base);
-    const uint32_t total = (uint32_t)a.n_samples << lg;
-
-    l.acc[lane] = 0ull; l.acc[lane + 64] = 0ull; l.acc[lane + 128] = 0ull;
-    if (lane < npx) {
-        const PixelRef ref = pixel_of(a, lin_base + lane);
-        l.out_px[lane] = ref.out;
-        T::prologue(a, ctx, lane, ref);
-    }
-    // One wave touches this LDS slice, in program order: no barrier needed.
-
-    typename T::Path path;
-    if (T::STEP_IDLE_LANES) T::idle(path);
-    uint32_t my_px = 0;
-    bool active = false;
-    uint32_t next = 0;   // wave-uniform
-    for (;;) {
-        const unsigned long long want = __ballot(!active);
-        if (want != 0ull && next < total) {
-            const uint32_t w = next + prefix_count(want);
-            next += (uint32_t)__popcll(want);
-            if (!active && w < total) {
-                const uint32_t px = w & (P - 1u), smp = w >> lg;
-                if (px < npx) {
-                    my_px = px;
-                    T::start(path, a, ctx, px, lin_base + px, smp);
-                    active = true;
-                }
-            }
-        }
-        T::phase(ctx, 0);
-        if (__ballot(active) == 0ull) {
-            if (next >= total) break;
-            continue;
-        }
-        if (T::STEP_IDLE_LANES) {
-            // Lanes without a path step whatever state they hold (a finished path or the idle ray) and the result is
-            // dropped: the wave spends the same time, and the path state has one definition per iteration instead of a
-            // merge of "stepped" and "left alone" that costs a round of register copies.
-            const bool go_on = T::step(path, a, ctx);
-            T::phase(ctx, 5);
-            if (active && !go_on) {
-                float rgb[3];
-                T::radiance(path, rgb);
-                add_sample(l, my_px, rgb);
-                active = false;
-            }
-        } else if (active) {
-            const bool go_on = T::step(path, a, ctx);
-            T::phase(ctx, 5);
-            if (!go_on) {
-                float rgb[3];
-                T::radiance(path, rgb);
-                add_sample(l, my_px, rgb);
-                active = false;
-            }
-        }
-        T::phase(ctx, 6);
-    }
-    store_tile(a, l, npx, lane);
-}
-
-// render_tile with the camera rays made 64 at a time.  Handing out work inside render_tile runs T::start for the
-// lanes whose path just ended, about 27 of 64 per iteration, at the price of a full wave.  Here all 64 lanes make the
-// rays of the next 64 pool items at once and park them in `stash` (LDS, one float4 per item: direction and RNG key);
-// a lane that needs work takes the next parked ray.  Items are still handed out in pool order, lane by lane, so the
-// assignment of samples to lanes is the one render_tile makes.
-// T additionally supplies:  static void make_ray(const RenderArgs&, Ctx&, uint32_t px, uint32_t sample, float4& ray);
-//                           static void begin(Path&, const RenderArgs&, Ctx&, const float4& ray);
-template <class T, class Ctx>
-__device__ __forceinline__ void render_tile_stash(const RenderArgs& a, uint32_t tile, WaveLds& l, float4* stash, Ctx& ctx) {
+__device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, WaveLds& l, float4* stash, Ctx& ctx) {
     const unsigned lane = lane_id();
     const uint32_t lg = (uint32_t)a.tile_log2, P = 1u << lg;
     const uint32_t lin_base = tile << lg;
@@ -218,13 +150,27 @@ __device__ __forceinline__ void render_tile_stash(const RenderArgs& a, uint32_t 
             if (taken >= total) break;
             continue;
         }
-        const bool go_on = T::step(path, a, ctx);      // idle lanes step too, see render_tile
-        T::phase(ctx, 5);
-        if (active && !go_on) {
-            float rgb[3];
-            T::radiance(path, rgb);
-            add_sample(l, my_px, rgb);
-            active = false;
+        if (T::STEP_IDLE_LANES) {
+            // Lanes without a path step whatever state they hold (a finished path or the idle ray) and the result is
+            // dropped: the wave spends the same time, and the path state has one definition per iteration instead of a
+            // merge of "stepped" and "left alone" that costs a round of register copies.
+            const bool go_on = T::step(path, a, ctx);
+            T::phase(ctx, 5);
+            if (active && !go_on) {
+                float rgb[3];
+                T::radiance(path, rgb);
+                add_sample(l, my_px, rgb);
+                active = false;
+            }
+        } else if (active) {
+            const bool go_on = T::step(path, a, ctx);
+            T::phase(ctx, 5);
+            if (!go_on) {
+                float rgb[3];
+                T::radiance(path, rgb);
+                add_sample(l, my_px, rgb);
+                active = false;
+            }
         }
         T::phase(ctx, 6);
     }
@@ -234,7 +180,7 @@ __device__ __forceinline__ void render_tile_stash(const RenderArgs& a, uint32_t 
 // The same pool, for tracers whose nearest-hit search is a WORKGROUP-wide operation (records staged through LDS
 // with barriers inside): every wave of the block calls this, also one whose tile lies beyond the image, and all
 // of them keep taking part in the search until the last wave of the block has drained its pool.
-// T additionally supplies:  static void idle(Path&);                                  // a ray nothing can hit
+// T additionally supplies:  static void start(Path&, const RenderArgs&, Ctx&, uint32_t px, uint32_t lin, uint32_t sample);   // make_ray + begin
 //                           static Best nearest_block(const Path&, const RenderArgs&, Ctx&);   // contains barriers
 //                           static bool shade(Path&, const Best&, const RenderArgs&, Ctx&);    // true = path continues
 template <class T, class Ctx>
