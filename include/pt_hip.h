@@ -168,6 +168,45 @@ int pt_trace_paths_alt(const pt_scene* scene, const float* d_o, const float* d_d
 int pt_rng_draws(int device, uint32_t seed, uint32_t pixel, uint32_t sample, int n_slots,
                  uint32_t* d_bits, float* d_uniforms, void* stream);
 
+/* ---- Several GPUs on one frame ------------------------------------------------
+ * The reference launches render once on one GPU (main.cu:236); nothing below has
+ * a counterpart there.  Rank r of `world` renders image rows r, r+world, ... with
+ * pt_render (row_begin = r, row_step = world, fb_compact = 1) into a tile of
+ * pt_tile_rows(height, world) rows; pt_gather_framebuffer all-gathers the tiles
+ * with RCCL (over xGMI inside a node) and writes the rows in image order, so every
+ * rank ends up with the whole AoS frame, bit for bit the single-GPU one.
+ * RCCL is loaded on the first pt_comm_* call, not when this library is. */
+typedef struct pt_comm pt_comm;
+#define PT_COMM_ID_BYTES 128
+
+/* ceil(height / world): rows per rank in the gathered layout (the last ranks'
+ * tiles may hold one row fewer; their last row is padding). */
+int pt_tile_rows(int height, int world);
+
+/* One process per GPU: rank 0 makes the id, the host program hands a copy to
+ * every rank (its own launcher, a file, MPI ...), all ranks then call
+ * pt_comm_init_rank, which blocks until all have.  (ncclGetUniqueId /
+ * ncclCommInitRank.) */
+int pt_comm_unique_id(char id[PT_COMM_ID_BYTES]);
+int pt_comm_init_rank(const char id[PT_COMM_ID_BYTES], int rank, int world, int device, pt_comm** out);
+/* One process driving `world` GPUs, one host thread per GPU: fills out[0..world)
+ * (ncclCommInitAll).  The threads then call pt_gather_framebuffer concurrently,
+ * each with its own communicator. */
+int pt_comm_init_all(int world, const int* devices, pt_comm** out);
+int pt_comm_free(pt_comm* comm);
+int pt_comm_rank(const pt_comm* comm);
+int pt_comm_world(const pt_comm* comm);
+
+/* d_tile: this rank's compact tile, pt_tile_rows x width x 3 floats;
+ * d_gathered: world x pt_tile_rows x width x 3 floats of scratch owned by the
+ * caller; d_full: height x width x 3, the assembled frame.  All on the
+ * communicator's device, ordered on `stream`; every rank must call it. */
+int pt_gather_framebuffer(pt_comm* comm, const float* d_tile, float* d_gathered, float* d_full,
+                          int height, int width, void* stream);
+/* The reordering step alone: gathered[r][k] -> image row k*world + r, launched on
+ * `stream` (the null stream: the calling thread's current device). */
+int pt_assemble_rows(const float* d_gathered, float* d_full, int height, int width, int world, void* stream);
+
 /* PPM P3 text of a host AoS framebuffer exactly as main.cu:240-253 prints it.
  * Returns the byte count, or -1 if cap is too small. */
 long pt_ppm_p3(const float* fb, int nx, int ny, char* out, long cap);

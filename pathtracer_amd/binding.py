@@ -78,6 +78,15 @@ def _load():
     L.pt_pfm.restype = C.c_long
     L.pt_pfm.argtypes = [vp, i32, i32, C.c_char_p, C.c_long]
     L.pt_scene_parse.argtypes = [C.c_char_p, C.POINTER(pt_prim), i32, C.POINTER(pt_material), i32, C.POINTER(i32)]
+    L.pt_tile_rows.argtypes = [i32, i32]
+    L.pt_comm_unique_id.argtypes = [C.c_char_p]
+    L.pt_comm_init_rank.argtypes = [C.c_char_p, i32, i32, i32, C.POINTER(vp)]
+    L.pt_comm_init_all.argtypes = [i32, C.POINTER(i32), C.POINTER(vp)]
+    L.pt_comm_free.argtypes = [vp]
+    L.pt_comm_rank.argtypes = [vp]
+    L.pt_comm_world.argtypes = [vp]
+    L.pt_gather_framebuffer.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    L.pt_assemble_rows.argtypes = [vp, vp, i32, i32, i32, vp]
     return L
 
 
@@ -88,6 +97,8 @@ EXPORTS = [
     "pt_synthetic_scene", "pt_focal_length", "pt_render", "pt_raypath_batch", "pt_nearest_batch",
     "pt_trace_paths", "pt_trace_paths_alt", "pt_rng_draws", "pt_ppm_p3", "pt_last_error", "pt_version",
     "pt_scene_parse", "pt_ppm_p6", "pt_pfm",
+    "pt_tile_rows", "pt_comm_unique_id", "pt_comm_init_rank", "pt_comm_init_all", "pt_comm_free", "pt_comm_rank",
+    "pt_comm_world", "pt_gather_framebuffer", "pt_assemble_rows",
 ]
 
 
@@ -294,3 +305,51 @@ def rng_draws(seed, pixel, sample, n_slots, device=0):
     with torch.cuda.device(device):
         _check(lib.pt_rng_draws(device, seed, pixel, sample, n_slots, _ptr(bits), _ptr(u), _stream()))
     return bits, u
+
+
+PT_COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """The id rank 0 makes and hands to every rank (ncclGetUniqueId)."""
+    buf = C.create_string_buffer(PT_COMM_ID_BYTES)
+    _check(lib.pt_comm_unique_id(buf))
+    return buf.raw
+
+
+def assemble_rows(gathered, full, height, width, world):
+    """gathered[r][k] -> image row k*world + r, on the current stream."""
+    assert gathered.is_contiguous() and full.is_contiguous()
+    assert gathered.numel() >= world * lib.pt_tile_rows(height, world) * width * 3 and full.numel() >= height * width * 3
+    with _torch().cuda.device(full.device):
+        _check(lib.pt_assemble_rows(_ptr(gathered), _ptr(full), height, width, world, _stream()))
+    return full
+
+
+class Comm:
+    """One rank's RCCL communicator (pt_comm_init_rank / pt_comm_free) and the gather of the ranks' row tiles."""
+
+    def __init__(self, unique_id, rank, world, device=0):
+        assert len(unique_id) == PT_COMM_ID_BYTES
+        self.rank, self.world, self.device = rank, world, device
+        h = C.c_void_p(0)
+        _check(lib.pt_comm_init_rank(unique_id, rank, world, device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.pt_comm_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def gather(self, tile, gathered, full, height, width):
+        """pt_gather_framebuffer on the current stream: every rank gets the assembled [height, width, 3] frame."""
+        rows = lib.pt_tile_rows(height, self.world)
+        assert tile.is_contiguous() and gathered.is_contiguous() and full.is_contiguous()
+        assert tile.numel() >= rows * width * 3 and gathered.numel() >= self.world * rows * width * 3
+        assert full.numel() >= height * width * 3
+        with _torch().cuda.device(self.device):
+            _check(lib.pt_gather_framebuffer(self.h, _ptr(tile), _ptr(gathered), _ptr(full), height, width, _stream()))
+        return full

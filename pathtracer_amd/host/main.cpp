@@ -5,7 +5,10 @@
 //   --width 800 --height 800 --spp 2000 --depth 5 --seed 0 --math fast --bsdf reference|classes
 //   --scene default|glass[N]|synthetic  --scene-file FILE  --format p3|p6|pfm  --gpus 1  --stats
 //   --tiles T (default = gpus): the image is split into T interleaved row sets, set k rendered on GPU k % gpus
+//   --gather host|rccl: tiles copied to the host image one by one (default), or all-gathered between the GPUs with RCCL
 // Usage, as in the reference's readme:  pathtracer > out.ppm
+#include <unistd.h>
+
 #include <chrono>
 #include <cmath>
 #include <fstream>
@@ -115,7 +118,7 @@ int main(int argc, char** argv) {
     int nx = 800, ny = 800, n_gpus = 1, n_tiles = 0;
     render_options opt;                 // n_samples 2000, n_bounces 5 as in the reference
     std::string scene_name = "default", scene_file, format = "p3";
-    bool stats = false;
+    bool stats = false, gather_rccl = false;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() -> const char* { if (i + 1 >= argc) { std::cerr << "missing value for " << a << "\n"; std::exit(2); } return argv[++i]; };
@@ -131,6 +134,7 @@ int main(int argc, char** argv) {
         else if (a == "--format") format = next();
         else if (a == "--gpus") n_gpus = std::atoi(next());
         else if (a == "--tiles") n_tiles = std::atoi(next());
+        else if (a == "--gather") gather_rccl = std::string(next()) == "rccl";
         else if (a == "--stats") stats = true;
         else { std::cerr << "unknown flag " << a << "\n"; return 2; }
     }
@@ -191,6 +195,25 @@ int main(int argc, char** argv) {
     const size_t num_pixels = (size_t)nx * ny;
     std::vector<vec3> fb(num_pixels);
     std::vector<double> ms(n_tiles, 0.0);
+    /* --gather rccl: one row set per GPU; the tiles are all-gathered over xGMI (pt_gather_framebuffer), every GPU ends
+       up with the whole frame and GPU 0's copy goes to the host.  Default: each tile is copied to the host image. */
+    std::vector<pt_comm*> comms;
+    if (gather_rccl) {
+        n_tiles = n_gpus;
+        std::vector<int> devices((size_t)n_gpus);
+        for (int g = 0; g < n_gpus; g++) devices[(size_t)g] = g;
+        comms.assign((size_t)n_gpus, nullptr);
+        /* RCCL may print a version banner on stdout while it starts; stdout carries the image, so it goes to stderr. */
+        std::cout.flush(); std::fflush(stdout);
+        const int saved_stdout = dup(STDOUT_FILENO);
+        dup2(STDERR_FILENO, STDOUT_FILENO);
+        const int rc = pt_comm_init_all(n_gpus, devices.data(), comms.data());
+        std::fflush(stdout);
+        dup2(saved_stdout, STDOUT_FILENO);
+        close(saved_stdout);
+        if (rc != 0) { std::cerr << pt_last_error() << "\n"; return 99; }
+    }
+    const int tile_rows = pt_tile_rows(ny, n_tiles);
     auto worker = [&](int k) {
         const int g = k % n_gpus;
         checkHipErrors(hipSetDevice(g));
@@ -198,14 +221,14 @@ int main(int argc, char** argv) {
         o.device = g;
         o.row_begin = k; o.row_end = ny; o.row_step = n_tiles; o.fb_compact = 1;
         const int my_rows = k < ny ? (ny - k + n_tiles - 1) / n_tiles : 0;
-        if (my_rows == 0) return;
+        if (my_rows == 0 && !gather_rccl) return;
         pt::DeviceScene dscene(scene.data(), n_objs, g);
         vec3* d_fb = nullptr;
-        checkHipErrors(hipMalloc((void**)&d_fb, (size_t)my_rows * nx * sizeof(vec3)));
+        checkHipErrors(hipMalloc((void**)&d_fb, (size_t)tile_rows * nx * sizeof(vec3)));
         hipEvent_t e0, e1;
         checkHipErrors(hipEventCreate(&e0)); checkHipErrors(hipEventCreate(&e1));
         checkHipErrors(hipEventRecord(e0, nullptr));
-        render(d_fb, config, dscene, o);
+        if (my_rows > 0) render(d_fb, config, dscene, o);
         checkHipErrors(hipEventRecord(e1, nullptr));
         checkHipErrors(hipGetLastError());
         checkHipErrors(hipDeviceSynchronize());
@@ -213,13 +236,27 @@ int main(int argc, char** argv) {
         checkHipErrors(hipEventElapsedTime(&t, e0, e1));
         ms[k] = t;
         const size_t row_bytes = (size_t)nx * sizeof(vec3);
-        checkHipErrors(hipMemcpy2D(fb.data() + (size_t)k * nx, row_bytes * n_tiles, d_fb, row_bytes, row_bytes, my_rows, hipMemcpyDeviceToHost));
+        if (gather_rccl) {
+            float *d_gathered = nullptr, *d_full = nullptr;
+            checkHipErrors(hipMalloc((void**)&d_gathered, (size_t)n_tiles * tile_rows * row_bytes));
+            checkHipErrors(hipMalloc((void**)&d_full, (size_t)ny * row_bytes));
+            if (pt_gather_framebuffer(comms[(size_t)k], reinterpret_cast<const float*>(d_fb), d_gathered, d_full, ny, nx, nullptr) != 0) {
+                std::cerr << pt_last_error() << "\n";
+                std::exit(99);
+            }
+            checkHipErrors(hipDeviceSynchronize());
+            if (k == 0) checkHipErrors(hipMemcpy(fb.data(), d_full, (size_t)ny * row_bytes, hipMemcpyDeviceToHost));
+            checkHipErrors(hipFree(d_gathered)); checkHipErrors(hipFree(d_full));
+        } else {
+            checkHipErrors(hipMemcpy2D(fb.data() + (size_t)k * nx, row_bytes * n_tiles, d_fb, row_bytes, row_bytes, my_rows, hipMemcpyDeviceToHost));
+        }
         checkHipErrors(hipFree(d_fb));
     };
     std::vector<std::thread> threads;
     for (int k = 1; k < n_tiles; k++) threads.emplace_back(worker, k);
     worker(0);
     for (auto& t : threads) t.join();
+    for (pt_comm* c : comms) pt_comm_free(c);
 
     if (stats) {
         double worst = 0.0;

@@ -73,3 +73,13 @@ def test_host_program_interleaved_tiles_and_alternative_bsdf():
     alt = subprocess.run([_need("pathtracer")] + args + ["--bsdf", "classes", "--tiles", "2"], capture_output=True, timeout=120)
     img = pt.Scene(*pt.default_scene()).render(pt.make_config(80, 50, 4, bsdf_model=pt.PT_BSDF_CLASSES)).cpu().numpy()
     assert alt.returncode == 0 and alt.stdout == pt.pfm(img) and alt.stdout != one.stdout
+
+
+def test_host_program_rccl_gather_on_one_device():
+    """--gather rccl: the tiles travel through pt_comm_init_all + pt_gather_framebuffer instead of per-tile host
+    copies (one GPU here, so a communicator of one rank); same file."""
+    args = ["--width", "80", "--height", "50", "--spp", "4", "--format", "pfm"]
+    one = subprocess.run([_need("pathtracer")] + args, capture_output=True, timeout=120)
+    r = subprocess.run([_need("pathtracer")] + args + ["--gather", "rccl"], capture_output=True, timeout=180)
+    assert one.returncode == 0 and r.returncode == 0, r.stderr.decode()
+    assert r.stdout == one.stdout
