@@ -313,6 +313,40 @@ void build_bvh(const std::vector<Baked>& baked, std::vector<int>& ids, int lo, i
     nodes[me].skip = (int32_t)nodes.size();
 }
 
+// The fat form of a skip-link tree whose leaves hold one primitive each: one entry per inner node, in the same
+// depth-first order, each with the boxes and references of its two children (left child = next node, right child =
+// the left child's skip link).
+// Returns the depth of the deepest leaf (the root's children are at depth 1): the walk parks at most one reference
+// per level, so this is the stack height a lane can need.
+int build_fat(const std::vector<BNode>& nodes, std::vector<BFat>& fat) {
+    std::vector<int32_t> fat_index(nodes.size(), -1);
+    int32_t n_inner = 0;
+    for (size_t i = 0; i < nodes.size(); i++) if (nodes[i].leaf < 0) fat_index[i] = n_inner++;
+    fat.assign((size_t)n_inner, BFat());
+    auto ref_of = [&](size_t i) { return nodes[i].leaf < 0 ? fat_index[i] : ~(int32_t)(nodes[i].leaf >> 4); };
+    for (size_t i = 0; i < nodes.size(); i++) {
+        if (nodes[i].leaf >= 0) continue;
+        const size_t a = i + 1, b = (size_t)nodes[i + 1].skip;
+        BFat& f = fat[(size_t)fat_index[i]];
+        std::memset(&f, 0, sizeof(f));
+        for (int k = 0; k < 3; k++) {
+            f.lo_a[k] = nodes[a].lo[k]; f.hi_a[k] = nodes[a].hi[k];
+            f.lo_b[k] = nodes[b].lo[k]; f.hi_b[k] = nodes[b].hi[k];
+        }
+        f.ref_a = ref_of(a); f.ref_b = ref_of(b);
+    }
+    // depth-first order: a node's depth is one more than that of the nearest earlier node whose subtree holds it
+    int depth = 0;
+    std::vector<std::pair<int32_t, int>> open;   // (skip link, depth) of the enclosing inner nodes
+    for (size_t i = 0; i < nodes.size(); i++) {
+        while (!open.empty() && (size_t)open.back().first <= i) open.pop_back();
+        const int d = open.empty() ? 0 : open.back().second + 1;
+        if (nodes[i].leaf < 0) open.push_back({nodes[i].skip, d});
+        else depth = std::max(depth, d);
+    }
+    return depth;
+}
+
 }  // namespace
 
 int pt_set_error(int code, const char* expr, const char* file, int line) {
@@ -420,12 +454,18 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
     const int n_chunks = pack_runs(baked, all, fdata, runs, chunk_runs);
     std::vector<BNode> bnodes;
     std::vector<BPrim> bprims;
+    std::vector<BFat> bfat;
+    int fat_depth = 0;
     int bvh_min = BVH_MIN_PRIMS;
     if (const char* e = std::getenv("PT_BVH_MIN")) { const int v = std::atoi(e); if (v >= 2) bvh_min = v; }
     if ((int)finite.size() >= bvh_min) {
         int leaf_prims = BVH_LEAF_PRIMS;
         if (const char* e = std::getenv("PT_BVH_LEAF")) { const int v = std::atoi(e); if (v >= 1 && v <= 15) leaf_prims = v; }
         build_bvh(baked, finite, 0, (int)finite.size(), bnodes, bprims, leaf_prims);
+        if (leaf_prims == 1 && finite.size() >= 2 && (int)finite.size() <= BFAT_MAX_PRIMS) {
+            fat_depth = build_fat(bnodes, bfat);
+            if (fat_depth > WALK_STACK_MAX) bfat.clear();   // cannot happen for a median split over <= 2^19 leaves
+        }
         if (top.empty()) {   // the loop over the other primitives still wants one (empty) chunk to read
             fdata_top.assign(FDATA_CHUNK + 16, 0.0f);
         } else {
@@ -457,6 +497,7 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
     if (!bnodes.empty()) {
         UP(d_bnodes, bnodes, BNode)
         UP(d_bprims, bprims, BPrim)
+        if (!bfat.empty()) { UP(d_bfat, bfat, BFat) sc->fat_depth = fat_depth; }
         UP(d_fdata_top, fdata_top, float)
         if (!runs_top.empty()) { UP(d_runs_top, runs_top, FRun) }
         sc->n_bnodes = (int)bnodes.size();
@@ -478,6 +519,7 @@ int pt_scene_free(pt_scene* sc) {
     if (sc->d_fshade) (void)hipFree(sc->d_fshade);
     if (sc->d_bnodes) (void)hipFree(sc->d_bnodes);
     if (sc->d_bprims) (void)hipFree(sc->d_bprims);
+    if (sc->d_bfat) (void)hipFree(sc->d_bfat);
     if (sc->d_fdata_top) (void)hipFree(sc->d_fdata_top);
     if (sc->d_runs_top) (void)hipFree(sc->d_runs_top);
     delete sc;
@@ -544,8 +586,12 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
         // PT_MATH_FAST walks the hierarchy for the finite primitives and loops over the rest;
         // PT_MATH_FAST_SCALAR and PT_MATH_FAST_LDS keep testing every primitive.
         a.bnodes = sc->d_bnodes; a.bprims = sc->d_bprims; a.n_bnodes = sc->n_bnodes;
+        a.bfat = sc->d_bfat; a.walk_stack = sc->fat_depth;
+        if (const char* e = std::getenv("PT_BVH_WALK")) { if (std::strcmp(e, "skip") == 0) { a.bfat = nullptr; a.walk_budget = 32; } }
         a.fdata = sc->d_fdata_top; a.runs = sc->d_runs_top; a.n_runs = sc->n_runs_top;
-        a.walk_budget = 32; a.shade_gate = 8;    // measured optimum on the 10 000-primitive scene is flat around these
+        // measured optimum on the 10 000-primitive scene is flat around these (a visit of the fat form decides
+        // about two boxes, so its budget is half the skip-link form's)
+        a.walk_budget = sc->d_bfat ? 16 : 32; a.shade_gate = 8;
         if (const char* e = std::getenv("PT_WALK_BUDGET")) { const int v = std::atoi(e); if (v >= 1) a.walk_budget = v; }
         if (const char* e = std::getenv("PT_SHADE_GATE")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) a.shade_gate = v; }
     }

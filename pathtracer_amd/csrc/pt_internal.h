@@ -84,6 +84,19 @@ struct BPrim {
     int32_t id;
     int32_t pad[2];
 };
+// The same tree with both children's boxes in the parent, for the ordered walk with a per-lane stack: one visit
+// fetches 64 bytes and decides about two subtrees.  A child reference is an index into this array (>= 0) or, for a
+// one-primitive leaf, ~(index into the BPrim array).  Built when every leaf holds one primitive and the tree has at
+// most 2^19 of them (references are packed into 20 bits on the stack).
+struct BFat {
+    float lo_a[3]; int32_t ref_a;
+    float hi_a[3]; int32_t ref_b;
+    float lo_b[3]; int32_t pad0;
+    float hi_b[3]; int32_t pad1;
+};
+constexpr int BFAT_MAX_PRIMS = 1 << 19;
+constexpr int WALK_STACK_MAX = 24;    // stack entries per lane: a median-split tree over 2^19 leaves is 19 levels deep
+constexpr int WALK_NONE = 0x7fffffff; // "no node in hand": the next one comes off the stack
 constexpr int BVH_MIN_PRIMS = 96;    // fewer finite primitives than this: no hierarchy, the loop tests them all (measured
                                      // crossover: ~60 tiny scattered shapes, above 65 large glass spheres at depth 31)
 constexpr int BVH_LEAF_PRIMS = 1;     // measured on the 10 000-primitive scene: 1 is fastest (24.4 ms), 4: 27.7, 8: 29.5
@@ -106,6 +119,8 @@ struct pt_scene {
     BNode* d_bnodes;
     int n_bnodes;
     BPrim* d_bprims;
+    BFat* d_bfat;                          // or null: only the skip-link form exists
+    int fat_depth;                         // depth of its deepest leaf = stack entries a lane can need
     float* d_fdata_top;
     FRun* d_runs_top;
     int n_runs_top;
@@ -137,6 +152,8 @@ struct RenderArgs {
     const FShade* fshade;
     const BNode* bnodes;                   // hierarchy over the finite primitives, or n_bnodes = 0
     const BPrim* bprims;
+    const BFat* bfat;                      // non-null: walk this form (ordered, per-lane stack in LDS)
+    int32_t walk_stack;                    // stack entries per lane the launch provides (dynamic LDS)
     int32_t n_bnodes;
     int32_t walk_budget;                   // hierarchy nodes a lane visits per loop iteration
     int32_t shade_gate;                    // lanes whose search is over before they are shaded together

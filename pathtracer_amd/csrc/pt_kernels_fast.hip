@@ -150,7 +150,12 @@ template <class RP> PTD void test_sphere(RP R, V3 o, V3 d, int id, Best& b) {
 template <class RP> PTD void test_cube(RP R, V3 o, V3 d, int id, Best& b) {
     const V3 ol = v3(row_point(R, o), row_point(R + 4, o), row_point(R + 8, o));
     const V3 dl = v3(row_vec(R, d), row_vec(R + 4, d), row_vec(R + 8, d));
-    const float ix = rcp(dl.x), iy = rcp(dl.y), iz = rcp(dl.z);
+    // 1/d kept finite: with an infinite reciprocal (a direction component of exactly 0) the entry / exit distances
+    // below would be inf - inf = NaN, which v_min / v_max drop, and a ray running beside the cube would hit it.  With
+    // +-1e30 instead they come out as the reference's (-0.5 - o)/0 and (0.5 - o)/0 do (shapes.h:172-177): both far
+    // negative or both far positive outside the slab, one of each inside it.
+    const float ix = __builtin_amdgcn_fmed3f(rcp(dl.x), -1e30f, 1e30f), iy = __builtin_amdgcn_fmed3f(rcp(dl.y), -1e30f, 1e30f),
+                iz = __builtin_amdgcn_fmed3f(rcp(dl.z), -1e30f, 1e30f);
     const float hx = 0.5f * __builtin_fabsf(ix), hy = 0.5f * __builtin_fabsf(iy), hz = 0.5f * __builtin_fabsf(iz);
     // entry / exit distance per slab
     const float nx = __builtin_fmaf(-ol.x, ix, -hx), ny = __builtin_fmaf(-ol.y, iy, -hy), nz = __builtin_fmaf(-ol.z, iz, -hz);
@@ -298,6 +303,73 @@ PTD void walk_hierarchy(V3 o, V3 d, float dd, float idd, const BNode* __restrict
     }
 }
 
+// The same search through the fat form of the tree (both children's boxes in the parent), nearer child first, the
+// other one parked on a per-lane stack in LDS (`stack`: this lane's column, entries 64 words apart).  A parked
+// entry keeps the top 12 bits of its box's entry distance above the 20-bit reference, so a subtree that a hit found
+// in the meantime has put out of reach is dropped when it comes off the stack without touching memory.  `cur` is
+// the reference in hand (WALK_NONE: take the next one off the stack), `sp` the stack height; the search is over
+// when cur == WALK_NONE and sp == 0.  Same result as walk_hierarchy: the order of the visits does not matter to
+// the (distance, scene index) rule the leaves apply.
+PTD void walk_fat(V3 o, V3 d, float dd, float idd, const BFat* __restrict__ fat, const BPrim* __restrict__ prims,
+                  Best& b, int& cur, int& sp, uint32_t* stack, int budget) {
+    const V3 inv = v3(rcp(d.x), rcp(d.y), rcp(d.z));
+    const V3 noi = v3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+    for (;;) {
+        while (budget > 0) {
+            if (cur == WALK_NONE) {
+                if (sp == 0) break;
+                const uint32_t e = stack[(--sp) * 64];
+                if (__uint_as_float(e & 0xFFF00000u) > b.t) continue;
+                cur = (e & 0x80000u) ? ~(int)(e & 0x7FFFFu) : (int)(e & 0x7FFFFu);
+            }
+            if (cur < 0) break;                     // a leaf: test it below, together with the other lanes' leaves
+            budget--;
+            const float4* N = reinterpret_cast<const float4*>(fat + cur);
+            const float4 A0 = N[0], A1 = N[1], B0 = N[2], B1 = N[3];
+            // slab tests of both boxes as plane*inv - o*inv; a NaN (0 * inf) drops out of v_min/v_max and leaves
+            // its axis unconstrained: conservative
+            const float a0x = __builtin_fmaf(A0.x, inv.x, noi.x), a1x = __builtin_fmaf(A1.x, inv.x, noi.x);
+            const float a0y = __builtin_fmaf(A0.y, inv.y, noi.y), a1y = __builtin_fmaf(A1.y, inv.y, noi.y);
+            const float a0z = __builtin_fmaf(A0.z, inv.z, noi.z), a1z = __builtin_fmaf(A1.z, inv.z, noi.z);
+            const float b0x = __builtin_fmaf(B0.x, inv.x, noi.x), b1x = __builtin_fmaf(B1.x, inv.x, noi.x);
+            const float b0y = __builtin_fmaf(B0.y, inv.y, noi.y), b1y = __builtin_fmaf(B1.y, inv.y, noi.y);
+            const float b0z = __builtin_fmaf(B0.z, inv.z, noi.z), b1z = __builtin_fmaf(B1.z, inv.z, noi.z);
+            const float tna = max3(__builtin_fminf(a0x, a1x), __builtin_fminf(a0y, a1y), __builtin_fmaxf(__builtin_fminf(a0z, a1z), 0.0f));
+            const float tfa = min3(__builtin_fmaxf(a0x, a1x), __builtin_fmaxf(a0y, a1y), __builtin_fminf(__builtin_fmaxf(a0z, a1z), b.t));
+            const float tnb = max3(__builtin_fminf(b0x, b1x), __builtin_fminf(b0y, b1y), __builtin_fmaxf(__builtin_fminf(b0z, b1z), 0.0f));
+            const float tfb = min3(__builtin_fmaxf(b0x, b1x), __builtin_fmaxf(b0y, b1y), __builtin_fminf(__builtin_fmaxf(b0z, b1z), b.t));
+            const bool ha = tna <= tfa, hb = tnb <= tfb;
+            const int ra = __float_as_int(A0.w), rb = __float_as_int(A1.w);
+            if (ha && hb) {
+                const bool a_first = tna <= tnb;
+                const int far = a_first ? rb : ra;
+                const float tfar = a_first ? tnb : tna;
+                const uint32_t packed = far < 0 ? (0x80000u | (uint32_t)~far) : (uint32_t)far;
+                stack[sp * 64] = (__float_as_uint(tfar) & 0xFFF00000u) | packed;
+                sp++;
+                cur = a_first ? ra : rb;
+            } else {
+                cur = ha ? ra : (hb ? rb : WALK_NONE);
+            }
+        }
+        if (cur >= 0) break;                        // nothing in hand (finished) or an inner node and no budget left
+        const BPrim* q = prims + ~cur;
+        cur = WALK_NONE;
+        Best c;
+        c.t = b.t < __builtin_inff() ? __uint_as_float(__float_as_uint(b.t) + 1u) : b.t;   // accept t <= b.t
+        c.id = -8;
+        const float* R = q->rec;
+        const int id = q->id;
+        switch (q->kind) {
+            case FP_SPHERE_WS: test_sphere_ws(R, o, d, dd, idd, id, c); break;
+            case FP_CUBE: test_cube(R, o, d, id, c); break;
+            case FP_SPHERE: test_sphere(R, o, d, id, c); break;
+            default: test_cylinder(R, o, d, id, c); break;
+        }
+        if (c.id >= 0 && (c.t < b.t || c.id < b.id)) b = c;
+    }
+}
+
 struct Surf {
     V3 pos, nrm;     // world position; unit normal facing against the ray
     bool inside;
@@ -370,6 +442,11 @@ struct Path {
 // and the new state side by side (every early return used to cost a round of register copies per iteration).
 PTD bool path_shade(Path& p, const Best& b0, const FShade* shade, const DMat* mats, int n_bounces, PhaseClock& clk) {
     const bool hit = b0.id >= 0;
+#ifdef PT_DEBUG_KEYS
+    { const uint32_t dk[] = {PT_DEBUG_KEYS};
+      for (uint32_t q : dk) if (p.key == q) printf("DBG key %08x seg %d o %08x %08x %08x d %08x %08x %08x t %08x (%g) id %d\n", p.key, p.seg,
+          __float_as_uint(p.o.x), __float_as_uint(p.o.y), __float_as_uint(p.o.z), __float_as_uint(p.d.x), __float_as_uint(p.d.y), __float_as_uint(p.d.z), __float_as_uint(b0.t), b0.t, b0.id); }
+#endif
     Best b = b0;
     b.id = hit ? b0.id : 0;                            // a miss reads primitive 0's records and is dropped at the end
     const Surf s = surface(b, p.o, p.d, shade);
@@ -514,6 +591,7 @@ struct SceneRefs {
     const BNode* nodes;
     const BPrim* bprims;
     int n_nodes;
+    const BFat* fat;
 };
 
 // One iteration of the tracePath loop (bsdf.h:78-166); true = continue.
@@ -532,6 +610,7 @@ PTD bool path_step(Path& p, const SceneRefs& sc, const FShade* shade, const DMat
 // iterations of the wave's loop, so its state travels with the path.
 struct WalkPath : Path {
     int node;      // -1: the segment's search has not begun; otherwise the hierarchy node to go on from
+    int sp;        // height of the lane's stack (fat form only)
     Best best;
 };
 
@@ -540,17 +619,25 @@ struct WalkPath : Path {
 // Instead every lane visits at most walk_budget nodes per iteration, and lanes whose search is over are shaded
 // (and start their next segment) once shade_gate of them have gathered or nobody is searching any more, so that
 // the shading code does not run for one or two lanes at a time.
+template <bool FAT>
 PTD bool path_step_walk(WalkPath& p, const SceneRefs& sc, const FShade* shade, const DMat* mats, int n_bounces,
-                        int bsdf_model, int walk_budget, int shade_gate, PhaseClock& clk) {
+                        int bsdf_model, int walk_budget, int shade_gate, uint32_t* stack, PhaseClock& clk) {
     const float dd = dot(p.d, p.d), idd = rcp(dd);
     if (p.node < 0) {
         p.best = best_none();
         scan_runs(p.o, p.d, dd, idd, as_constant(sc.fdata), as_constant(sc.runs), 0, sc.n_runs, p.best);
         p.node = 0;
+        p.sp = 0;
     }
-    walk_hierarchy(p.o, p.d, dd, idd, sc.nodes, sc.n_nodes, sc.bprims, p.best, p.node, walk_budget);
+    bool done;
+    if (FAT) {
+        walk_fat(p.o, p.d, dd, idd, sc.fat, sc.bprims, p.best, p.node, p.sp, stack, walk_budget);
+        done = p.node == WALK_NONE && p.sp == 0;
+    } else {
+        walk_hierarchy(p.o, p.d, dd, idd, sc.nodes, sc.n_nodes, sc.bprims, p.best, p.node, walk_budget);
+        done = p.node >= sc.n_nodes;
+    }
     PHASE(clk, 1);
-    const bool done = p.node >= sc.n_nodes;
     const unsigned long long done_m = __ballot(done), busy_m = __ballot(!done);
     if (!done || (__popcll(done_m) < shade_gate && busy_m != 0ull)) return true;
     p.node = -1;
@@ -572,14 +659,16 @@ struct FastCtx {
     const DMat* mats;      // LDS or global
     float* pxt;            // LDS, this wave's [3][64]: i-0.5, H-j-0.5, K_px bits
     float* stage;          // LDS, FDATA_CHUNK floats shared by the workgroup (LDS-tiled kernel only)
+    uint32_t* wstack;      // LDS, this lane's column of the wave's walk stack (fat hierarchy only)
     PhaseClock clk;
 };
 
-template <bool BVH>
+// BVH: 0 = loop over all primitives, 1 = hierarchy in skip-link form, 2 = hierarchy in fat form.
+template <int BVH>
 struct FastTracer {
-    using Path = typename std::conditional<BVH, ptf::WalkPath, ptf::Path>::type;
+    using Path = typename std::conditional<BVH != 0, ptf::WalkPath, ptf::Path>::type;
     // The hierarchy walk counts lanes (shade gate), so there only lanes with a path step.
-    static constexpr bool STEP_IDLE_LANES = !BVH;
+    static constexpr bool STEP_IDLE_LANES = BVH == 0;
     // Lane px prepares pixel px of the tile: jitter-free sample-plane coordinates
     // (main.cu:62) and the pixel's RNG key.
     static PTD void prologue(const RenderArgs& a, FastCtx& c, uint32_t px, const ptw::PixelRef& ref) {
@@ -620,22 +709,23 @@ struct FastTracer {
         begin_search(p);
     }
     static PTD void begin_search(ptf::Path&) {}
-    static PTD void begin_search(ptf::WalkPath& p) { p.node = -1; }
+    static PTD void begin_search(ptf::WalkPath& p) { p.node = -1; p.sp = 0; }
     static PTD bool step(Path& p, const RenderArgs& a, FastCtx& c) {
         SceneRefs sc;
         sc.fdata = a.fdata; sc.runs = a.runs; sc.n_runs = a.n_runs;
-        sc.nodes = a.bnodes; sc.bprims = a.bprims; sc.n_nodes = a.n_bnodes;
+        sc.nodes = a.bnodes; sc.bprims = a.bprims; sc.n_nodes = a.n_bnodes; sc.fat = a.bfat;
         return step_path(p, sc, a, c);
     }
     static PTD bool step_path(ptf::Path& p, const SceneRefs& sc, const RenderArgs& a, FastCtx& c) {
         return path_step<false>(p, sc, c.shade, c.mats, a.n_bounces, a.bsdf_model, c.clk);
     }
     static PTD bool step_path(ptf::WalkPath& p, const SceneRefs& sc, const RenderArgs& a, FastCtx& c) {
-        return path_step_walk(p, sc, c.shade, c.mats, a.n_bounces, a.bsdf_model, a.walk_budget, a.shade_gate, c.clk);
+        return path_step_walk<BVH == 2>(p, sc, c.shade, c.mats, a.n_bounces, a.bsdf_model, a.walk_budget, a.shade_gate, c.wstack, c.clk);
     }
     static PTD void idle(Path& p) {
         p.o = v3(0.0f, 0.0f, 0.0f); p.d = v3(0.0f, 0.0f, 0.0f);
         p.coef = v3(0.0f, 0.0f, 0.0f); p.contrib = v3(0.0f, 0.0f, 0.0f); p.key = 0; p.seg = 0;
+        begin_search(p);
     }
     // getNearestIntersection with the records staged through LDS: EVERY thread of the workgroup calls this
     // (it contains barriers); lanes without a path carry a zero ray, which no test accepts.
@@ -662,11 +752,12 @@ struct FastTracer {
     static PTD void phase(FastCtx& c, int i) { PHASE(c.clk, i); (void)c; (void)i; }
 };
 
-template <bool LDS_TABLES, bool BVH>
+template <bool LDS_TABLES, int BVH>
 __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, uint32_t n_tiles) {
     __shared__ ptw::WaveLds lds[ptw::WAVES_PER_BLOCK];
     __shared__ float pxt[ptw::WAVES_PER_BLOCK][192];
     __shared__ float4 stash[ptw::WAVES_PER_BLOCK][64];
+    extern __shared__ uint32_t wstack[];   // BVH == 2: [waves][a.walk_stack][64], sized by the launch
     __shared__ FShade lshade[LDS_TABLES ? LDS_MAX_PRIMS : 1];
     __shared__ DMat lmats[LDS_TABLES ? LDS_MAX_MATS : 1];
     FastCtx ctx;
@@ -687,6 +778,7 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, u
     const uint32_t tile = blockIdx.x * ptw::WAVES_PER_BLOCK + wave;
     if (tile >= n_tiles) return;
     ctx.pxt = pxt[wave];
+    ctx.wstack = BVH == 2 ? wstack + wave * ((uint32_t)a.walk_stack * 64u) + (threadIdx.x & 63u) : nullptr;
     ctx.clk.start();
     ptw::render_tile<FastTracer<BVH>>(a, tile, lds[wave], stash[wave], ctx);
     ctx.clk.flush(threadIdx.x & 63);
@@ -717,7 +809,7 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_tiled_kernel(RenderArg
     ctx.pxt = pxt[wave];
     ctx.stage = stage;
     ctx.clk.start();
-    ptw::render_tile_blocksync<FastTracer<false>>(a, tile, tile < n_tiles, lds[wave], ctx);
+    ptw::render_tile_blocksync<FastTracer<0>>(a, tile, tile < n_tiles, lds[wave], ctx);
     ctx.clk.flush(threadIdx.x & 63);
 }
 
@@ -764,14 +856,20 @@ int ptk_render_fast(const RenderArgs& a, int variant, hipStream_t s) {
         else
             hipLaunchKernelGGL(render_fast_tiled_kernel<false>, dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
     } else if (a.n_bnodes > 0) {
-        if (a.n_mats <= LDS_MAX_MATS && a.n_prims <= LDS_MAX_PRIMS)
-            hipLaunchKernelGGL((render_fast_kernel<true, true>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
-        else
-            hipLaunchKernelGGL((render_fast_kernel<false, true>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+        const bool tables = a.n_mats <= LDS_MAX_MATS && a.n_prims <= LDS_MAX_PRIMS;
+        if (a.bfat) {
+            // the walk stacks: one column of a.walk_stack entries per lane
+            const size_t stack_bytes = (size_t)ptw::WAVES_PER_BLOCK * (size_t)a.walk_stack * 64u * sizeof(uint32_t);
+            if (tables) hipLaunchKernelGGL((render_fast_kernel<true, 2>), dim3(blocks), dim3(ptw::BLOCK), stack_bytes, s, a, n_tiles);
+            else hipLaunchKernelGGL((render_fast_kernel<false, 2>), dim3(blocks), dim3(ptw::BLOCK), stack_bytes, s, a, n_tiles);
+        } else {
+            if (tables) hipLaunchKernelGGL((render_fast_kernel<true, 1>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+            else hipLaunchKernelGGL((render_fast_kernel<false, 1>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+        }
     } else if (a.n_prims <= LDS_MAX_PRIMS && a.n_mats <= LDS_MAX_MATS)
-        hipLaunchKernelGGL((render_fast_kernel<true, false>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+        hipLaunchKernelGGL((render_fast_kernel<true, 0>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
     else
-        hipLaunchKernelGGL((render_fast_kernel<false, false>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+        hipLaunchKernelGGL((render_fast_kernel<false, 0>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
     PT_CHECK(hipGetLastError());
     return 0;
 }
@@ -782,12 +880,12 @@ int ptk_trace_paths_fast(const pt_scene* sc, const float* o, const float* d, con
     SceneRefs refs;
     if (sc->n_bnodes > 0) {
         refs.fdata = sc->d_fdata_top; refs.runs = sc->d_runs_top; refs.n_runs = sc->n_runs_top;
-        refs.nodes = sc->d_bnodes; refs.bprims = sc->d_bprims; refs.n_nodes = sc->n_bnodes;
+        refs.nodes = sc->d_bnodes; refs.bprims = sc->d_bprims; refs.n_nodes = sc->n_bnodes; refs.fat = nullptr;
         hipLaunchKernelGGL(trace_fast_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, s, refs,
                            sc->d_fshade, sc->d_mats, o, d, pixel, sample, n, seed_hash, n_bounces, bsdf_model, rgb);
     } else {
         refs.fdata = sc->d_fdata; refs.runs = sc->d_runs; refs.n_runs = sc->n_runs;
-        refs.nodes = nullptr; refs.bprims = nullptr; refs.n_nodes = 0;
+        refs.nodes = nullptr; refs.bprims = nullptr; refs.n_nodes = 0; refs.fat = nullptr;
         hipLaunchKernelGGL(trace_fast_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, s, refs,
                            sc->d_fshade, sc->d_mats, o, d, pixel, sample, n, seed_hash, n_bounces, bsdf_model, rgb);
     }

@@ -1,6 +1,7 @@
 """GPU parity for BASELINE configs 4 and 5 at sizes the oracle finishes in seconds:
 the glass-grid stress scene at depth 31 and the 10 000-primitive synthetic scene."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -189,3 +190,53 @@ def test_more_materials_and_primitives_than_the_lds_tables_hold(oracle):
     print("41 materials / 73 primitives: parity rmse %.2e bad %.5f | fast rmse %.2e bad %.5f" % (rp, bp, rf, bf))
     assert rp <= 0.01 and bp <= 0.001
     assert bf <= 0.02
+
+
+def test_direction_components_of_exactly_zero(oracle):
+    """Rays with one or two direction components of exactly 0 (1/d infinite) that run beside, into and inside every
+    shape type: both kernel families find what the oracle finds.  A fast cube test once computed its slab distances
+    as inf - inf there and reported a hit for a ray passing beside the cube."""
+    import torch
+    import pathtracer_amd as pt
+    text = """
+material glow emissive 3 2 1
+material dark albedo 0 0 0
+cube glow      translate 0 -0.5 -4.2  scale 2.5 0.3 0.5
+sphere glow    translate 2 0 -3       scale 0.8
+cylinder glow  translate -2 0 -3      scale 0.6 0.6 1.2
+sphere glow    translate 0 2 -3       scale 0.9 0.5 0.7
+plane glow     bounds -0.5 -0.5 0.5 0.5  translate 0 -2 -3
+"""
+    prims, n, mats, nm = pt.parse_scene(text)
+    rng = np.random.default_rng(77)
+    N = 6000
+    centres = np.array([[0, -0.5, -4.2], [2, 0, -3], [-2, 0, -3], [0, 2, -3], [0, -2, -3]], np.float32)
+    o = (centres[rng.integers(0, 5, N)] + rng.uniform(-1.6, 1.6, (N, 3))).astype(np.float32)
+    d = rng.normal(size=(N, 3)).astype(np.float32)
+    zero = rng.integers(0, 3, N)
+    d[np.arange(N), zero] = 0.0
+    two = rng.random(N) < 0.3
+    d[np.arange(N)[two], (zero[two] + 1) % 3] = 0.0
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    assert (d == 0).any(axis=1).all()
+    # the ray of the original failure: beside the cube, d.y = 0
+    o[0] = (1.0, 0.8554, -3.825); d[0] = (-0.9468, 0.0, -0.3217); d[0] /= np.linalg.norm(d[0])
+    px = np.arange(N, dtype=np.int32); sm = np.zeros(N, np.int32)
+    osc = oracle.Scene(*_as_oracle(oracle, prims, n, mats, nm))
+    ref = osc.trace_paths(o, d, px.astype(np.uint32), sm.astype(np.uint32), seed=0, n_bounces=0)
+    assert (ref.sum(axis=1) > 0).mean() > 0.03 and (ref.sum(axis=1) == 0).mean() > 0.1
+    assert ref[0].sum() == 0
+    for bvh_min in ("2", "1000000"):              # through the hierarchy and through the loop
+        os.environ["PT_BVH_MIN"] = bvh_min
+        try:
+            sc = pt.Scene(prims, n, mats, nm)
+        finally:
+            del os.environ["PT_BVH_MIN"]
+        for mode in (pt.PT_MATH_PARITY, pt.PT_MATH_FAST):
+            rgb = sc.trace_paths(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda(), torch.from_numpy(px).cuda(),
+                                 torch.from_numpy(sm).cuda(), seed=0, n_bounces=0, math_mode=mode).cpu().numpy()
+            differ = (rgb != ref).any(axis=1)
+            # emission is added unscaled at the first hit, so a ray's radiance is (3,2,1) or 0: any difference is a
+            # different hit decision; grazing rays may flip in the fast build
+            assert differ.mean() <= (0.0 if mode == pt.PT_MATH_PARITY else 2e-3), (bvh_min, mode, differ.sum())
+            assert not differ[0]
