@@ -240,3 +240,58 @@ plane glow     bounds -0.5 -0.5 0.5 0.5  translate 0 -2 -3
             # different hit decision; grazing rays may flip in the fast build
             assert differ.mean() <= (0.0 if mode == pt.PT_MATH_PARITY else 2e-3), (bvh_min, mode, differ.sum())
             assert not differ[0]
+
+
+def _random_scene_text(rng, n_shapes):
+    """Shapes of all four types under random rotations, non-uniform scales and translations; shape k glows with
+    (k+1, 0.5, 0.25), so the radiance of a depth-0 path names the primitive it hit."""
+    lines = []
+    for k in range(n_shapes):
+        lines.append("material m%d emissive %d 0.5 0.25" % (k, k + 1))
+    for k in range(n_shapes):
+        kind = ("plane", "cube", "cylinder", "sphere")[k % 4]
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        s = rng.uniform(0.3, 1.5, 3)
+        if kind == "sphere" and k % 8 == 3:
+            s[:] = s[0]                                   # uniformly scaled spheres take the world-space test
+        t = rng.uniform(-3, 3, 3) + np.array([0, 0, -6.0])
+        opt = "rotate %.6f %.6f %.6f %.6f translate %.5f %.5f %.5f scale %.5f %.5f %.5f" % (rng.uniform(0, 6.28), ax[0], ax[1], ax[2], t[0], t[1], t[2], s[0], s[1], s[2])
+        if kind == "plane":
+            opt = "bounds -1.2 -0.7 0.9 1.4 " + opt
+        lines.append("%s m%d %s" % (kind, k, opt))
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("n_shapes,seed", [(12, 1), (40, 2), (160, 3)])
+def test_fast_hit_decisions_on_random_scenes(oracle, n_shapes, seed):
+    """Which primitive a ray hits first, fast kernels (loop and hierarchy) against the oracle, on random affine shapes
+    and random rays: the parity-order kernels are compared bit by bit elsewhere, this pins the restructured tests of
+    the fast kernels (folded plane bounds, world-space spheres, slab cube, cylinder case analysis)."""
+    import torch
+    import pathtracer_amd as pt
+    rng = np.random.default_rng(seed)
+    prims, n, mats, nm = pt.parse_scene(_random_scene_text(rng, n_shapes), max_prims=n_shapes, max_mats=n_shapes)
+    assert n == n_shapes
+    N = 20000
+    o = (rng.uniform(-4, 4, (N, 3)) + np.array([0, 0, -6.0])).astype(np.float32)
+    target = rng.uniform(-3.5, 3.5, (N, 3)) + np.array([0, 0, -6.0])
+    d = target - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    px = np.arange(N, dtype=np.int32); sm = np.zeros(N, np.int32)
+    osc = oracle.Scene(*_as_oracle(oracle, prims, n, mats, nm))
+    ref = osc.trace_paths(o, d, px.astype(np.uint32), sm.astype(np.uint32), seed=0, n_bounces=0)
+    hit_frac = (ref[:, 0] > 0).mean()
+    assert hit_frac > 0.3
+    assert len(np.unique(ref[:, 0])) >= min(n_shapes, 10)          # many different primitives are first hits
+    for bvh_min in ("2", "1000000"):
+        os.environ["PT_BVH_MIN"] = bvh_min
+        try:
+            sc = pt.Scene(prims, n, mats, nm)
+        finally:
+            del os.environ["PT_BVH_MIN"]
+        for mode in (pt.PT_MATH_PARITY, pt.PT_MATH_FAST):
+            rgb = sc.trace_paths(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda(), torch.from_numpy(px).cuda(),
+                                 torch.from_numpy(sm).cuda(), seed=0, n_bounces=0, math_mode=mode).cpu().numpy()
+            differ = (rgb != ref).any(axis=1)
+            print("random scene %d shapes, bvh_min %s, mode %d: first hit differs for %d of %d rays" % (n_shapes, bvh_min, mode, differ.sum(), N))
+            assert differ.mean() <= (0.0 if mode == pt.PT_MATH_PARITY else 1e-3), (bvh_min, mode, int(differ.sum()))
