@@ -23,7 +23,8 @@
 
 // Development aid (make prof): per-phase shader-cycle shares of the render loop, stamped with s_memtime.
 // Phases: 0 refill, 1 nearest, 2 surface + material fetch, 3 emissive/Beer/Fresnel/mode, 4 direction, 5 throughput +
-// roulette, 6 accumulate.  Not compiled into libpt_hip.so.
+// roulette, 6 accumulate, 7 (hierarchy kernels) the loop over the primitives outside the hierarchy.  Not compiled into
+// libpt_hip.so.
 #ifdef PT_PHASE_PROF
 __device__ unsigned long long g_phase_cycles[16];   // [0..7] cycles, [8..15] cycles x active lanes at the stamp
 struct PhaseClock {
@@ -629,6 +630,7 @@ PTD bool path_step_walk(WalkPath& p, const SceneRefs& sc, const FShade* shade, c
         p.node = 0;
         p.sp = 0;
     }
+    PHASE(clk, 7);
     bool done;
     if (FAT) {
         walk_fat(p.o, p.d, dd, idd, sc.fat, sc.bprims, p.best, p.node, p.sp, stack, walk_budget);

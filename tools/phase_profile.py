@@ -24,7 +24,7 @@ assert prof.pt_render(hs, C.byref(cfg), C.c_void_p(fb.data_ptr()), None) == 0
 prof.pt_dev_phase_cycles(buf, 1)
 assert prof.pt_render(hs, C.byref(cfg), C.c_void_p(fb.data_ptr()), None) == 0
 prof.pt_dev_phase_cycles(buf, 1)
-names = ["refill", "nearest", "surface+material", "emissive/Beer/Fresnel/mode", "direction", "throughput+roulette", "accumulate", "-"]
+names = ["refill", "nearest", "surface+material", "emissive/Beer/Fresnel/mode", "direction", "throughput+roulette", "accumulate", "primitives outside the hierarchy"]
 tot = float(sum(buf[:8]))
-for k in range(7):
+for k in range(8):
     print("%-28s %6.2f %% of cycles, %5.1f %% of lanes active at the stamp" % (names[k], 100.0 * buf[k] / tot, 100.0 * buf[8 + k] / (64.0 * buf[k]) if buf[k] else 0.0))
