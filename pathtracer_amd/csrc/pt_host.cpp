@@ -267,6 +267,29 @@ int pack_runs(const std::vector<Baked>& baked, const std::vector<int>& ids, std:
     return n_chunks;
 }
 
+// Packs the records of primitives `ids` (ascending scene indices) sorted by kind, each with its scene index << 3
+// behind it (as int bits), at the kind's stride.  Offsets are 16-float aligned; 32 floats of padding follow the last
+// record because the loops fetch records two at a time.
+void pack_sorted(const std::vector<Baked>& baked, const std::vector<int>& ids, std::vector<float>& data, FSorted& hdr) {
+    std::memset(&hdr, 0, sizeof(hdr));
+    for (int kind = 0; kind < FP_KINDS; kind++) {
+        data.resize((data.size() + 15) / 16 * 16, 0.0f);
+        hdr.off[kind] = (int32_t)data.size();
+        const int stride = FSORTED_STRIDE[kind];
+        for (int k : ids) {
+            const Baked& b = baked[k];
+            if (b.kind != kind) continue;
+            const size_t at = data.size();
+            data.resize(at + (size_t)stride, 0.0f);
+            std::memcpy(&data[at], b.rec, (size_t)b.len * sizeof(float));
+            const int32_t id = (int32_t)(k << 3);
+            std::memcpy(&data[at + (size_t)b.len], &id, sizeof(id));
+            hdr.count[kind]++;
+        }
+    }
+    data.resize(data.size() + 32, 0.0f);
+}
+
 // Median-split hierarchy over ids[lo, hi), appended to `nodes` in depth-first order.  Boxes are padded so that
 // the rounding of the kernels' slab test can never cull a primitive its own test would accept.
 void build_bvh(const std::vector<Baked>& baked, std::vector<int>& ids, int lo, int hi, std::vector<BNode>& nodes,
@@ -452,6 +475,10 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
     std::vector<FRun> runs, runs_top;
     std::vector<int32_t> chunk_runs, chunk_runs_top;
     const int n_chunks = pack_runs(baked, all, fdata, runs, chunk_runs);
+    std::vector<float> sorted_all, sorted_top;
+    FSorted hdr_all, hdr_top;
+    pack_sorted(baked, all, sorted_all, hdr_all);
+    pack_sorted(baked, top, sorted_top, hdr_top);
     std::vector<BNode> bnodes;
     std::vector<BPrim> bprims;
     std::vector<BFat> bfat;
@@ -493,11 +520,15 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
     UP(d_chunk_runs, chunk_runs, int32_t)
     sc->n_chunks = n_chunks;
     UP(d_fshade, fs, FShade)
+    UP(d_sorted, sorted_all, float)
+    sc->sorted = hdr_all; sc->sorted.data = sc->d_sorted;
     sc->n_runs = (int)runs.size();
     if (!bnodes.empty()) {
         UP(d_bnodes, bnodes, BNode)
         UP(d_bprims, bprims, BPrim)
         if (!bfat.empty()) { UP(d_bfat, bfat, BFat) sc->fat_depth = fat_depth; }
+        UP(d_sorted_top, sorted_top, float)
+        sc->sorted_top = hdr_top; sc->sorted_top.data = sc->d_sorted_top;
         UP(d_fdata_top, fdata_top, float)
         if (!runs_top.empty()) { UP(d_runs_top, runs_top, FRun) }
         sc->n_bnodes = (int)bnodes.size();
@@ -520,6 +551,8 @@ int pt_scene_free(pt_scene* sc) {
     if (sc->d_bnodes) (void)hipFree(sc->d_bnodes);
     if (sc->d_bprims) (void)hipFree(sc->d_bprims);
     if (sc->d_bfat) (void)hipFree(sc->d_bfat);
+    if (sc->d_sorted) (void)hipFree(sc->d_sorted);
+    if (sc->d_sorted_top) (void)hipFree(sc->d_sorted_top);
     if (sc->d_fdata_top) (void)hipFree(sc->d_fdata_top);
     if (sc->d_runs_top) (void)hipFree(sc->d_runs_top);
     delete sc;
@@ -582,6 +615,7 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     a.prims = sc->d_prims; a.mats = sc->d_mats;
     a.fdata = sc->d_fdata; a.runs = sc->d_runs; a.n_runs = sc->n_runs; a.fshade = sc->d_fshade;
     a.chunk_runs = sc->d_chunk_runs; a.n_chunks = sc->n_chunks;
+    a.sorted = sc->sorted;
     if (sc->n_bnodes > 0 && cfg->math_mode == PT_MATH_FAST) {
         // PT_MATH_FAST walks the hierarchy for the finite primitives and loops over the rest;
         // PT_MATH_FAST_SCALAR and PT_MATH_FAST_LDS keep testing every primitive.
@@ -589,6 +623,7 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
         a.bfat = sc->d_bfat; a.walk_stack = sc->fat_depth;
         if (const char* e = std::getenv("PT_BVH_WALK")) { if (std::strcmp(e, "skip") == 0) { a.bfat = nullptr; a.walk_budget = 32; } }
         a.fdata = sc->d_fdata_top; a.runs = sc->d_runs_top; a.n_runs = sc->n_runs_top;
+        a.sorted = sc->sorted_top;
         // measured optimum on the 10 000-primitive scene is flat around these (a visit of the fat form decides
         // about two boxes, so its budget is half the skip-link form's)
         a.walk_budget = sc->d_bfat ? 16 : 32; a.shade_gate = 8;

@@ -41,11 +41,27 @@ struct DMat {
 //   FP_PLANE (12)     : row z of T^-1 (4) | row x scaled (4) | row y scaled (4)
 //                       — the scaled rows map the bounds to |x'| < 1, |y'| < 1
 //   FP_PLANE_GEN (16) : rows z, x, y of T^-1 (12) | xMin, yMin, xMax, yMax
+//   FP_PLANE_X/Y/Z (5): a bounded plane whose normal and edges run along world axes (normal along x/y/z, edges
+//                       along the other two, u < v): plane coordinate | centre, half-width along u | the same along v
 //   FP_SPHERE_WS (4)  : centre.xyz, radius^2   (L = s*R: tested in world space)
 //   FP_SPHERE, FP_CUBE, FP_CYLINDER (12): rows of T^-1
 // The float array is cut into chunks of FDATA_CHUNK floats; no record and no run crosses a chunk boundary, so a
 // workgroup can stage one chunk at a time in LDS (the LDS-tiled primitive loop for large scenes).
 constexpr int FDATA_CHUNK = 4096;
+
+enum { FP_PLANE = 0, FP_CUBE = 1, FP_CYLINDER = 2, FP_SPHERE = 3, FP_SPHERE_WS = 4, FP_PLANE_GEN = 5,
+       FP_PLANE_X = 6, FP_PLANE_Y = 7, FP_PLANE_Z = 8, FP_KINDS = 9 };
+
+// The same records sorted by kind (scene order within a kind), each followed by its primitive's scene index << 3 and
+// padded to a fixed stride per kind: what PT_MATH_FAST loops over.  No run table: six typed loops whose offsets and
+// counts travel in the kernel arguments.  The (distance, index) rule of the tests makes the result independent of
+// the order in which primitives are tested.
+struct FSorted {
+    const float* data;
+    int32_t off[FP_KINDS];     // by FP_*: first float of the kind's records
+    int32_t count[FP_KINDS];
+};
+constexpr int FSORTED_STRIDE[FP_KINDS] = {16, 16, 16, 16, 8, 20, 8, 8, 8};   // floats per record by FP_*; the index sits after the record
 
 struct FRun {
     int32_t type;     // FP_*
@@ -101,7 +117,7 @@ constexpr int BVH_MIN_PRIMS = 96;    // fewer finite primitives than this: no hi
                                      // crossover: ~60 tiny scattered shapes, above 65 large glass spheres at depth 31)
 constexpr int BVH_LEAF_PRIMS = 1;     // measured on the 10 000-primitive scene: 1 is fastest (24.4 ms), 4: 27.7, 8: 29.5
 
-enum { FP_PLANE = 0, FP_CUBE = 1, FP_CYLINDER = 2, FP_SPHERE = 3, FP_SPHERE_WS = 4, FP_PLANE_GEN = 5 };
+
 
 struct pt_scene {
     int device;
@@ -119,6 +135,10 @@ struct pt_scene {
     BNode* d_bnodes;
     int n_bnodes;
     BPrim* d_bprims;
+    float* d_sorted;                       // all primitives sorted by kind
+    FSorted sorted;
+    float* d_sorted_top;                   // the primitives outside the hierarchy sorted by kind
+    FSorted sorted_top;
     BFat* d_bfat;                          // or null: only the skip-link form exists
     int fat_depth;                         // depth of its deepest leaf = stack entries a lane can need
     float* d_fdata_top;
@@ -152,6 +172,7 @@ struct RenderArgs {
     const FShade* fshade;
     const BNode* bnodes;                   // hierarchy over the finite primitives, or n_bnodes = 0
     const BPrim* bprims;
+    FSorted sorted;                        // PT_MATH_FAST: the primitives the typed loops test (all, or those outside the hierarchy)
     const BFat* bfat;                      // non-null: walk this form (ordered, per-lane stack in LDS)
     int32_t walk_stack;                    // stack entries per lane the launch provides (dynamic LDS)
     int32_t n_bnodes;

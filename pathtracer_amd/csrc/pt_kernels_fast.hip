@@ -17,6 +17,7 @@
 #include "pt_internal.h"
 #include "pt_wavepool.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 #define PTD __device__ __forceinline__
@@ -96,9 +97,16 @@ struct Best {
                   // cylinder = surface 0 body, 1 disc +z, 2 disc -z
 };
 
-// Every test below ends the same way: the candidate replaces the best hit when
-// EPS < t < best.t (plus its own validity mask).  Strict '<' keeps the lowest
-// primitive index on ties, as getNearestIntersection does (shapes.h:93).
+// Every test below ends the same way: the candidate replaces the best hit when t > EPS (plus its own validity mask)
+// and (t, id) is below (best.t, best.id) in dictionary order.  Tested in scene order that is the strict '<' of
+// getNearestIntersection (shapes.h:93), which keeps the lowest primitive index on ties; written this way the result
+// does not depend on the order of the tests.  Positive floats order like their bit patterns; a negative or NaN t has
+// already failed t > EPS.
+PTD bool nearer(float t, int id, const Best& b) {
+    const unsigned long long kc = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)id;
+    const unsigned long long kb = ((unsigned long long)__float_as_uint(b.t) << 32) | (unsigned)b.id;
+    return kc < kb;
+}
 
 // Plane with the bounds folded into rows x', y' (record: z row | x' row | y' row).
 template <class RP> PTD void test_plane(RP R, V3 o, V3 d, int id, Best& b) {
@@ -107,7 +115,7 @@ template <class RP> PTD void test_plane(RP R, V3 o, V3 d, int id, Best& b) {
     const float t = -oz * rcp(dz);                 // dz == 0 gives inf/nan: every compare below fails
     const V3 p = madd(d, t, o);
     const float xl = row_point(R + 4, p), yl = row_point(R + 8, p);
-    const bool ok = (t > EPS) & (t < b.t) & (__builtin_fabsf(xl) < 1.0f) & (__builtin_fabsf(yl) < 1.0f);
+    const bool ok = (t > EPS) & nearer(t, id, b) & (__builtin_fabsf(xl) < 1.0f) & (__builtin_fabsf(yl) < 1.0f);
     b.t = ok ? t : b.t;
     b.id = ok ? id : b.id;
 }
@@ -119,7 +127,7 @@ template <class RP> PTD void test_plane_gen(RP R, V3 o, V3 d, int id, Best& b) {
     const float t = -oz * rcp(dz);
     const V3 p = madd(d, t, o);
     const float xl = row_point(R + 4, p), yl = row_point(R + 8, p);
-    const bool ok = (t > EPS) & (t < b.t) & (xl > R[12]) & (yl > R[13]) & (xl < R[14]) & (yl < R[15]);
+    const bool ok = (t > EPS) & nearer(t, id, b) & (xl > R[12]) & (yl > R[13]) & (xl < R[14]) & (yl < R[15]);
     b.t = ok ? t : b.t;
     b.id = ok ? id : b.id;
 }
@@ -131,7 +139,7 @@ PTD void take_quadratic(float a, float ia, float h, float c, int id, Best& b) {
     const float s = fsqrt(__builtin_fmaf(h, h, -a * c));
     const float t1 = (-h - s) * ia, t2 = (s - h) * ia;
     const float t = t1 > EPS ? t1 : t2;
-    const bool ok = (t > EPS) & (t < b.t);
+    const bool ok = (t > EPS) & nearer(t, id, b);
     b.t = ok ? t : b.t;
     b.id = ok ? id : b.id;
 }
@@ -165,7 +173,7 @@ template <class RP> PTD void test_cube(RP R, V3 o, V3 d, int id, Best& b) {
     const bool use_exit = !(tmin > EPS);
     const float t = use_exit ? tmax : tmin;
     // tmax >= 0 (shapes.h:191) is implied by t > EPS and tmin <= tmax.
-    const bool ok = (tmin <= tmax) & (t > EPS) & (t < b.t);
+    const bool ok = (tmin <= tmax) & (t > EPS) & nearer(t, id, b);
     if (ok) {
         const float ax = use_exit ? fx : nx, ay = use_exit ? fy : ny;
         const int axis = (ax == t) ? 0 : ((ay == t) ? 1 : 2);
@@ -212,7 +220,7 @@ template <class RP> PTD void test_cylinder(RP R, V3 o, V3 d, int id, Best& b) {
         else if (e1) { valid = h2; t = t2; s = s2; }
         else if (e2) { valid = h1; t = t1; s = s1; }
         else { const bool sec = t2 < t1; valid = sec ? h2 : h1; t = sec ? t2 : t1; s = sec ? s2 : s1; }
-        if (valid && t < b.t) { b.t = t; b.id = id | s; }
+        if (valid && nearer(t, id, b)) { b.t = t; b.id = id | s; }
     }
 }
 
@@ -254,6 +262,43 @@ PTD void scan_runs(V3 o, V3 d, float dd, float idd, RP base, KIntP runs, int r0,
     }
 }
 
+// The loop of getNearestIntersection over the kind-sorted records: one typed loop per kind, offsets and counts from
+// the kernel arguments (no run table to fetch, no switch).  Every index is wave-uniform, so records arrive by scalar
+// loads; a record's scene index << 3 sits right behind it.  Planes go two per trip: one wait covers both records.
+PTD void scan_sorted(V3 o, V3 d, float dd, float idd, const FSorted& S, Best& b) {
+    const KFloatP base = as_constant(S.data);
+    {
+        KFloatP R = base + S.off[FP_PLANE];
+        int i = 0;
+        const int n = S.count[FP_PLANE];
+        for (; i + 2 <= n; i += 2, R += 32) {
+            test_plane(R, o, d, __float_as_int(R[12]), b);
+            test_plane(R + 16, o, d, __float_as_int(R[28]), b);
+        }
+        if (i < n) test_plane(R, o, d, __float_as_int(R[12]), b);
+    }
+    {
+        KFloatP R = base + S.off[FP_PLANE_GEN];
+        for (int i = S.count[FP_PLANE_GEN]; i > 0; i--, R += 20) test_plane_gen(R, o, d, __float_as_int(R[16]), b);
+    }
+    {
+        KFloatP R = base + S.off[FP_SPHERE_WS];
+        for (int i = S.count[FP_SPHERE_WS]; i > 0; i--, R += 8) test_sphere_ws(R, o, d, dd, idd, __float_as_int(R[4]), b);
+    }
+    {
+        KFloatP R = base + S.off[FP_SPHERE];
+        for (int i = S.count[FP_SPHERE]; i > 0; i--, R += 16) test_sphere(R, o, d, __float_as_int(R[12]), b);
+    }
+    {
+        KFloatP R = base + S.off[FP_CUBE];
+        for (int i = S.count[FP_CUBE]; i > 0; i--, R += 16) test_cube(R, o, d, __float_as_int(R[12]), b);
+    }
+    {
+        KFloatP R = base + S.off[FP_CYLINDER];
+        for (int i = S.count[FP_CYLINDER]; i > 0; i--, R += 16) test_cylinder(R, o, d, __float_as_int(R[12]), b);
+    }
+}
+
 PTD Best best_none() { Best b; b.t = __builtin_inff(); b.id = -8; return b; }
 
 // The finite primitives through their bounding-volume hierarchy, per lane.  `b` comes in holding the best hit
@@ -288,18 +333,14 @@ PTD void walk_hierarchy(V3 o, V3 d, float dd, float idd, const BNode* __restrict
         if (leaf < 0) break;
         const BPrim* q = prims + (leaf >> 4);
         for (int k = leaf & 15; k > 0; k--, q++) {
-            Best c;
-            c.t = b.t < __builtin_inff() ? __uint_as_float(__float_as_uint(b.t) + 1u) : b.t;   // accept t <= b.t
-            c.id = -8;
             const float* R = q->rec;
             const int id = q->id;
             switch (q->kind) {
-                case FP_SPHERE_WS: test_sphere_ws(R, o, d, dd, idd, id, c); break;
-                case FP_CUBE: test_cube(R, o, d, id, c); break;
-                case FP_SPHERE: test_sphere(R, o, d, id, c); break;
-                default: test_cylinder(R, o, d, id, c); break;
+                case FP_SPHERE_WS: test_sphere_ws(R, o, d, dd, idd, id, b); break;
+                case FP_CUBE: test_cube(R, o, d, id, b); break;
+                case FP_SPHERE: test_sphere(R, o, d, id, b); break;
+                default: test_cylinder(R, o, d, id, b); break;
             }
-            if (c.id >= 0 && (c.t < b.t || c.id < b.id)) b = c;
         }
     }
 }
@@ -356,18 +397,14 @@ PTD void walk_fat(V3 o, V3 d, float dd, float idd, const BFat* __restrict__ fat,
         if (cur >= 0) break;                        // nothing in hand (finished) or an inner node and no budget left
         const BPrim* q = prims + ~cur;
         cur = WALK_NONE;
-        Best c;
-        c.t = b.t < __builtin_inff() ? __uint_as_float(__float_as_uint(b.t) + 1u) : b.t;   // accept t <= b.t
-        c.id = -8;
         const float* R = q->rec;
         const int id = q->id;
         switch (q->kind) {
-            case FP_SPHERE_WS: test_sphere_ws(R, o, d, dd, idd, id, c); break;
-            case FP_CUBE: test_cube(R, o, d, id, c); break;
-            case FP_SPHERE: test_sphere(R, o, d, id, c); break;
-            default: test_cylinder(R, o, d, id, c); break;
+            case FP_SPHERE_WS: test_sphere_ws(R, o, d, dd, idd, id, b); break;
+            case FP_CUBE: test_cube(R, o, d, id, b); break;
+            case FP_SPHERE: test_sphere(R, o, d, id, b); break;
+            default: test_cylinder(R, o, d, id, b); break;
         }
-        if (c.id >= 0 && (c.t < b.t || c.id < b.id)) b = c;
     }
 }
 
@@ -593,14 +630,16 @@ struct SceneRefs {
     const BPrim* bprims;
     int n_nodes;
     const BFat* fat;
+    FSorted sorted;       // data == null: loop over the runs instead
 };
 
 // One iteration of the tracePath loop (bsdf.h:78-166); true = continue.
-template <bool BVH>
+template <bool BVH, bool SORTED>
 PTD bool path_step(Path& p, const SceneRefs& sc, const FShade* shade, const DMat* mats, int n_bounces, int bsdf_model, PhaseClock& clk) {
     Best b = best_none();
     const float dd = dot(p.d, p.d), idd = rcp(dd);
-    scan_runs(p.o, p.d, dd, idd, as_constant(sc.fdata), as_constant(sc.runs), 0, sc.n_runs, b);
+    if (SORTED) scan_sorted(p.o, p.d, dd, idd, sc.sorted, b);
+    else scan_runs(p.o, p.d, dd, idd, as_constant(sc.fdata), as_constant(sc.runs), 0, sc.n_runs, b);
     if (BVH) { int n = 0; walk_hierarchy(p.o, p.d, dd, idd, sc.nodes, sc.n_nodes, sc.bprims, b, n, 0x7fffffff); }
     PHASE(clk, 1);
     if (bsdf_model == PT_BSDF_CLASSES) return path_shade_alt(p, b, shade, mats, n_bounces, clk);
@@ -626,7 +665,7 @@ PTD bool path_step_walk(WalkPath& p, const SceneRefs& sc, const FShade* shade, c
     const float dd = dot(p.d, p.d), idd = rcp(dd);
     if (p.node < 0) {
         p.best = best_none();
-        scan_runs(p.o, p.d, dd, idd, as_constant(sc.fdata), as_constant(sc.runs), 0, sc.n_runs, p.best);
+        scan_sorted(p.o, p.d, dd, idd, sc.sorted, p.best);
         p.node = 0;
         p.sp = 0;
     }
@@ -666,7 +705,8 @@ struct FastCtx {
 };
 
 // BVH: 0 = loop over all primitives, 1 = hierarchy in skip-link form, 2 = hierarchy in fat form.
-template <int BVH>
+// SORTED: the loop runs over the kind-sorted records (PT_MATH_FAST) instead of the runs in scene order.
+template <int BVH, bool SORTED>
 struct FastTracer {
     using Path = typename std::conditional<BVH != 0, ptf::WalkPath, ptf::Path>::type;
     // The hierarchy walk counts lanes (shade gate), so there only lanes with a path step.
@@ -715,11 +755,11 @@ struct FastTracer {
     static PTD bool step(Path& p, const RenderArgs& a, FastCtx& c) {
         SceneRefs sc;
         sc.fdata = a.fdata; sc.runs = a.runs; sc.n_runs = a.n_runs;
-        sc.nodes = a.bnodes; sc.bprims = a.bprims; sc.n_nodes = a.n_bnodes; sc.fat = a.bfat;
+        sc.nodes = a.bnodes; sc.bprims = a.bprims; sc.n_nodes = a.n_bnodes; sc.fat = a.bfat; sc.sorted = a.sorted;
         return step_path(p, sc, a, c);
     }
     static PTD bool step_path(ptf::Path& p, const SceneRefs& sc, const RenderArgs& a, FastCtx& c) {
-        return path_step<false>(p, sc, c.shade, c.mats, a.n_bounces, a.bsdf_model, c.clk);
+        return path_step<false, SORTED>(p, sc, c.shade, c.mats, a.n_bounces, a.bsdf_model, c.clk);
     }
     static PTD bool step_path(ptf::WalkPath& p, const SceneRefs& sc, const RenderArgs& a, FastCtx& c) {
         return path_step_walk<BVH == 2>(p, sc, c.shade, c.mats, a.n_bounces, a.bsdf_model, a.walk_budget, a.shade_gate, c.wstack, c.clk);
@@ -754,7 +794,7 @@ struct FastTracer {
     static PTD void phase(FastCtx& c, int i) { PHASE(c.clk, i); (void)c; (void)i; }
 };
 
-template <bool LDS_TABLES, int BVH>
+template <bool LDS_TABLES, int BVH, bool SORTED>
 __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, uint32_t n_tiles) {
     __shared__ ptw::WaveLds lds[ptw::WAVES_PER_BLOCK];
     __shared__ float pxt[ptw::WAVES_PER_BLOCK][192];
@@ -782,7 +822,7 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, u
     ctx.pxt = pxt[wave];
     ctx.wstack = BVH == 2 ? wstack + wave * ((uint32_t)a.walk_stack * 64u) + (threadIdx.x & 63u) : nullptr;
     ctx.clk.start();
-    ptw::render_tile<FastTracer<BVH>>(a, tile, lds[wave], stash[wave], ctx);
+    ptw::render_tile<FastTracer<BVH, SORTED>>(a, tile, lds[wave], stash[wave], ctx);
     ctx.clk.flush(threadIdx.x & 63);
 }
 
@@ -811,7 +851,7 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_tiled_kernel(RenderArg
     ctx.pxt = pxt[wave];
     ctx.stage = stage;
     ctx.clk.start();
-    ptw::render_tile_blocksync<FastTracer<0>>(a, tile, tile < n_tiles, lds[wave], ctx);
+    ptw::render_tile_blocksync<FastTracer<0, false>>(a, tile, tile < n_tiles, lds[wave], ctx);
     ctx.clk.flush(threadIdx.x & 63);
 }
 
@@ -829,7 +869,7 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(SceneRefs sc,
     p.d = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     p.coef = v3(1.0f, 1.0f, 1.0f); p.contrib = v3(0.0f, 0.0f, 0.0f); p.seg = 0;
     PhaseClock clk;
-    while (path_step<BVH>(p, sc, shade, mats, n_bounces, bsdf_model, clk)) {}
+    while (path_step<BVH, false>(p, sc, shade, mats, n_bounces, bsdf_model, clk)) {}
     rgb[3 * i] = p.contrib.x; rgb[3 * i + 1] = p.contrib.y; rgb[3 * i + 2] = p.contrib.z;
 }
 
@@ -862,16 +902,23 @@ int ptk_render_fast(const RenderArgs& a, int variant, hipStream_t s) {
         if (a.bfat) {
             // the walk stacks: one column of a.walk_stack entries per lane
             const size_t stack_bytes = (size_t)ptw::WAVES_PER_BLOCK * (size_t)a.walk_stack * 64u * sizeof(uint32_t);
-            if (tables) hipLaunchKernelGGL((render_fast_kernel<true, 2>), dim3(blocks), dim3(ptw::BLOCK), stack_bytes, s, a, n_tiles);
-            else hipLaunchKernelGGL((render_fast_kernel<false, 2>), dim3(blocks), dim3(ptw::BLOCK), stack_bytes, s, a, n_tiles);
+            if (tables) hipLaunchKernelGGL((render_fast_kernel<true, 2, true>), dim3(blocks), dim3(ptw::BLOCK), stack_bytes, s, a, n_tiles);
+            else hipLaunchKernelGGL((render_fast_kernel<false, 2, true>), dim3(blocks), dim3(ptw::BLOCK), stack_bytes, s, a, n_tiles);
         } else {
-            if (tables) hipLaunchKernelGGL((render_fast_kernel<true, 1>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
-            else hipLaunchKernelGGL((render_fast_kernel<false, 1>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+            if (tables) hipLaunchKernelGGL((render_fast_kernel<true, 1, true>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+            else hipLaunchKernelGGL((render_fast_kernel<false, 1, true>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
         }
-    } else if (a.n_prims <= LDS_MAX_PRIMS && a.n_mats <= LDS_MAX_MATS)
-        hipLaunchKernelGGL((render_fast_kernel<true, 0>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
-    else
-        hipLaunchKernelGGL((render_fast_kernel<false, 0>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+    } else {
+        const bool tables = a.n_prims <= LDS_MAX_PRIMS && a.n_mats <= LDS_MAX_MATS;
+        const bool sorted = variant == PT_MATH_FAST && std::getenv("PT_LOOP_RUNS") == nullptr;   // PT_MATH_FAST_SCALAR: the runs, in scene order
+        if (sorted) {
+            if (tables) hipLaunchKernelGGL((render_fast_kernel<true, 0, true>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+            else hipLaunchKernelGGL((render_fast_kernel<false, 0, true>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+        } else {
+            if (tables) hipLaunchKernelGGL((render_fast_kernel<true, 0, false>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+            else hipLaunchKernelGGL((render_fast_kernel<false, 0, false>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+        }
+    }
     PT_CHECK(hipGetLastError());
     return 0;
 }
