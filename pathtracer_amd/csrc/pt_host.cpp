@@ -170,6 +170,40 @@ int bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, float* rec, FSha
                     for (int j = 0; j < 3; j++) rec[4 + 4 * ax + j] = (float)(inv.m[ax][j] * sc[ax]);
                     rec[4 + 4 * ax + 3] = (float)((inv.m[ax][3] - cc[ax]) * sc[ax]);
                 }
+                // A plane whose normal and edges run along world axes (every row above has one entry that matters;
+                // what a rotation by (float)(pi/2) leaves where a zero belongs, ~4e-8 of it, counts as zero) gets the
+                // short test: t = (k - o_n)/d_n, then two interval tests on single coordinates.
+                int axis[3] = {-1, -1, -1};
+                bool aligned = std::getenv("PT_PLANE_AXIS") == nullptr || std::atoi(std::getenv("PT_PLANE_AXIS")) != 0;
+                for (int r = 0; r < 3 && aligned; r++) {
+                    const float* row = rec + 4 * r;
+                    int a = 0;
+                    for (int j = 1; j < 3; j++) if (fabsf(row[j]) > fabsf(row[a])) a = j;
+                    if (row[a] == 0.0f) { if (r == 0) aligned = false; continue; }   // an unbounded edge direction: no entry at all
+                    for (int j = 0; j < 3; j++) if (j != a && fabsf(row[j]) > 1e-6f * fabsf(row[a])) aligned = false;
+                    axis[r] = a;
+                }
+                if (aligned) {
+                    // edge rows without an entry take the axes that are left
+                    for (int r = 1; r < 3; r++) if (axis[r] < 0) for (int a = 0; a < 3; a++) if (a != axis[0] && a != axis[1] && a != axis[2]) { axis[r] = a; break; }
+                    aligned = axis[0] != axis[1] && axis[0] != axis[2] && axis[1] != axis[2];
+                }
+                if (aligned) {
+                    const int ru = axis[1] < axis[2] ? 1 : 2, rv = 3 - ru;   // u < v
+                    float out[5];
+                    out[0] = (float)(-(double)rec[3] / (double)rec[axis[0]]);
+                    const int rows[2] = {ru, rv};
+                    for (int e = 0; e < 2; e++) {
+                        const float* row = rec + 4 * rows[e];
+                        const float a = row[axis[rows[e]]];
+                        if (a == 0.0f) { out[1 + 2 * e] = 0.0f; out[2 + 2 * e] = INFINITY; }
+                        else { out[1 + 2 * e] = (float)(-(double)row[3] / (double)a); out[2 + 2 * e] = (float)(1.0 / fabs((double)a)); }
+                    }
+                    *ftype = FP_PLANE_X + axis[0];
+                    for (int j = 0; j < 5; j++) rec[j] = out[j];
+                    for (int j = 5; j < 16; j++) rec[j] = 0.0f;
+                    return 5;
+                }
                 return 12;
             }
             *ftype = FP_PLANE_GEN;

@@ -132,6 +132,19 @@ template <class RP> PTD void test_plane_gen(RP R, V3 o, V3 d, int id, Best& b) {
     b.id = ok ? id : b.id;
 }
 
+// Plane with its normal along world axis N and its edges along the other two (record: plane coordinate | centre and
+// half-width along the lower of the two axes | the same along the higher).  inv = 1/d.
+template <int N, class RP> PTD void test_plane_axis(RP R, V3 o, V3 d, V3 inv, int id, Best& b) {
+    const float on = N == 0 ? o.x : (N == 1 ? o.y : o.z), in = N == 0 ? inv.x : (N == 1 ? inv.y : inv.z);
+    const float ou = N == 0 ? o.y : o.x, du = N == 0 ? d.y : d.x;
+    const float ov = N == 2 ? o.y : o.z, dv = N == 2 ? d.y : d.z;
+    const float t = (R[0] - on) * in;              // d_n == 0 gives inf/nan: a compare below fails
+    const float pu = __builtin_fmaf(du, t, ou) - R[1], pv = __builtin_fmaf(dv, t, ov) - R[3];
+    const bool ok = (t > EPS) & nearer(t, id, b) & (__builtin_fabsf(pu) < R[2]) & (__builtin_fabsf(pv) < R[4]);
+    b.t = ok ? t : b.t;
+    b.id = ok ? id : b.id;
+}
+
 // Quadratic a t^2 + 2 h t + c = 0 with ia = 1/a: the root Shape::getIntersections
 // + getNearestIntersection keep is the smaller one if it is beyond EPS, else the
 // larger.  A negative discriminant makes s NaN and every compare false.
@@ -229,6 +242,7 @@ template <class RP> PTD void test_cylinder(RP R, V3 o, V3 d, int id, Best& b) {
 // global memory (records then arrive by scalar loads) or an LDS image of one chunk of it.
 template <class RP>
 PTD void scan_runs(V3 o, V3 d, float dd, float idd, RP base, KIntP runs, int r0, int r1, Best& b) {
+    const V3 inv = v3(rcp(d.x), rcp(d.y), rcp(d.z));
     for (int r = r0; r < r1; r++) {
         FRun run;
         run.type = runs[4 * r]; run.first = runs[4 * r + 1]; run.count = runs[4 * r + 2]; run.offset = runs[4 * r + 3];
@@ -255,6 +269,15 @@ PTD void scan_runs(V3 o, V3 d, float dd, float idd, RP base, KIntP runs, int r0,
             case FP_PLANE_GEN:
                 for (int i = 0; i < run.count; i++, R += 16, id += 8) test_plane_gen(R, o, d, id, b);
                 break;
+            case FP_PLANE_X:
+                for (int i = 0; i < run.count; i++, R += 5, id += 8) test_plane_axis<0>(R, o, d, inv, id, b);
+                break;
+            case FP_PLANE_Y:
+                for (int i = 0; i < run.count; i++, R += 5, id += 8) test_plane_axis<1>(R, o, d, inv, id, b);
+                break;
+            case FP_PLANE_Z:
+                for (int i = 0; i < run.count; i++, R += 5, id += 8) test_plane_axis<2>(R, o, d, inv, id, b);
+                break;
             default:
                 for (int i = 0; i < run.count; i++, R += 12, id += 8) test_cylinder(R, o, d, id, b);
                 break;
@@ -262,11 +285,27 @@ PTD void scan_runs(V3 o, V3 d, float dd, float idd, RP base, KIntP runs, int r0,
     }
 }
 
+// Axis-aligned planes of one kind, two per trip (records of 8 floats: five of data, the scene index << 3, padding).
+template <int N> PTD void axis_planes(KFloatP R, int n, V3 o, V3 d, V3 inv, Best& b) {
+    int i = 0;
+    for (; i + 2 <= n; i += 2, R += 16) {
+        test_plane_axis<N>(R, o, d, inv, __float_as_int(R[5]), b);
+        test_plane_axis<N>(R + 8, o, d, inv, __float_as_int(R[13]), b);
+    }
+    if (i < n) test_plane_axis<N>(R, o, d, inv, __float_as_int(R[5]), b);
+}
+
 // The loop of getNearestIntersection over the kind-sorted records: one typed loop per kind, offsets and counts from
 // the kernel arguments (no run table to fetch, no switch).  Every index is wave-uniform, so records arrive by scalar
 // loads; a record's scene index << 3 sits right behind it.  Planes go two per trip: one wait covers both records.
 PTD void scan_sorted(V3 o, V3 d, float dd, float idd, const FSorted& S, Best& b) {
     const KFloatP base = as_constant(S.data);
+    if (S.count[FP_PLANE_X] + S.count[FP_PLANE_Y] + S.count[FP_PLANE_Z] > 0) {
+        const V3 inv = v3(rcp(d.x), rcp(d.y), rcp(d.z));
+        axis_planes<0>(base + S.off[FP_PLANE_X], S.count[FP_PLANE_X], o, d, inv, b);
+        axis_planes<1>(base + S.off[FP_PLANE_Y], S.count[FP_PLANE_Y], o, d, inv, b);
+        axis_planes<2>(base + S.off[FP_PLANE_Z], S.count[FP_PLANE_Z], o, d, inv, b);
+    }
     {
         KFloatP R = base + S.off[FP_PLANE];
         int i = 0;
