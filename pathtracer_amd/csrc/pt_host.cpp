@@ -232,9 +232,24 @@ int bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, float* rec, FSha
             return 12;
         }
         case PT_CUBE: {
+            for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) fs->a[j * 3 + i] = ncol[j][i];
+            // Diagonal L (off-diagonal entries below 1e-6 of their column's diagonal entry): the cube is a box along
+            // the world axes and is tested there, local axis i being world axis i.
+            bool diagonal = std::getenv("PT_CUBE_AXIS") == nullptr || std::atoi(std::getenv("PT_CUBE_AXIS")) != 0;
+            for (int j = 0; j < 3 && diagonal; j++) {
+                if (fwd.m[j][j] == 0.0f) diagonal = false;
+                for (int i = 0; i < 3; i++) if (i != j && fabsf(fwd.m[i][j]) > 1e-6f * fabsf(fwd.m[j][j])) diagonal = false;
+            }
+            if (diagonal) {
+                *ftype = FP_CUBE_AA;
+                for (int i = 0; i < 3; i++) {
+                    const float h = 0.5f * fabsf(fwd.m[i][i]);
+                    rec[i] = fwd.m[i][3] - h; rec[3 + i] = fwd.m[i][3] + h;
+                }
+                return 6;
+            }
             *ftype = FP_CUBE;
             put_inv();
-            for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) fs->a[j * 3 + i] = ncol[j][i];
             return 12;
         }
         default: {   // PT_CYLINDER

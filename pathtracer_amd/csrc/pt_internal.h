@@ -45,12 +45,13 @@ struct DMat {
 //                       along the other two, u < v): plane coordinate | centre, half-width along u | the same along v
 //   FP_SPHERE_WS (4)  : centre.xyz, radius^2   (L = s*R: tested in world space)
 //   FP_SPHERE, FP_CUBE, FP_CYLINDER (12): rows of T^-1
+//   FP_CUBE_AA (6)    : a cube under a diagonal L (no rotation): world-space box, low corner | high corner
 // The float array is cut into chunks of FDATA_CHUNK floats; no record and no run crosses a chunk boundary, so a
 // workgroup can stage one chunk at a time in LDS (the LDS-tiled primitive loop for large scenes).
 constexpr int FDATA_CHUNK = 4096;
 
 enum { FP_PLANE = 0, FP_CUBE = 1, FP_CYLINDER = 2, FP_SPHERE = 3, FP_SPHERE_WS = 4, FP_PLANE_GEN = 5,
-       FP_PLANE_X = 6, FP_PLANE_Y = 7, FP_PLANE_Z = 8, FP_KINDS = 9 };
+       FP_PLANE_X = 6, FP_PLANE_Y = 7, FP_PLANE_Z = 8, FP_CUBE_AA = 9, FP_KINDS = 10 };
 
 // The same records sorted by kind (scene order within a kind), each followed by its primitive's scene index << 3 and
 // padded to a fixed stride per kind: what PT_MATH_FAST loops over.  No run table: six typed loops whose offsets and
@@ -61,7 +62,7 @@ struct FSorted {
     int32_t off[FP_KINDS];     // by FP_*: first float of the kind's records
     int32_t count[FP_KINDS];
 };
-constexpr int FSORTED_STRIDE[FP_KINDS] = {16, 16, 16, 16, 8, 20, 8, 8, 8};   // floats per record by FP_*; the index sits after the record
+constexpr int FSORTED_STRIDE[FP_KINDS] = {16, 16, 16, 16, 8, 20, 8, 8, 8, 8};   // floats per record by FP_*; the index sits after the record
 
 struct FRun {
     int32_t type;     // FP_*

@@ -195,6 +195,27 @@ template <class RP> PTD void test_cube(RP R, V3 o, V3 d, int id, Best& b) {
     }
 }
 
+// Cube under a diagonal transform, as its world-space box (record: low corner | high corner); inv = 1/d, infinite
+// where a direction component is 0: both planes of that slab are then at -inf, at +inf, or one each, as in
+// shapes.h:172-177.  Codes as test_cube.
+template <class RP> PTD void test_cube_box(RP R, V3 o, V3 inv, int id, Best& b) {
+    const float x0 = (R[0] - o.x) * inv.x, x1 = (R[3] - o.x) * inv.x;
+    const float y0 = (R[1] - o.y) * inv.y, y1 = (R[4] - o.y) * inv.y;
+    const float z0 = (R[2] - o.z) * inv.z, z1 = (R[5] - o.z) * inv.z;
+    const float nx = __builtin_fminf(x0, x1), ny = __builtin_fminf(y0, y1), nz = __builtin_fminf(z0, z1);
+    const float fx = __builtin_fmaxf(x0, x1), fy = __builtin_fmaxf(y0, y1), fz = __builtin_fmaxf(z0, z1);
+    const float tmin = max3(nx, ny, nz), tmax = min3(fx, fy, fz);
+    const bool use_exit = !(tmin > EPS);
+    const float t = use_exit ? tmax : tmin;
+    const bool ok = (tmin <= tmax) & (t > EPS) & nearer(t, id, b);
+    if (ok) {
+        const float ax = use_exit ? fx : nx, ay = use_exit ? fy : ny;
+        const int axis = (ax == t) ? 0 : ((ay == t) ? 1 : 2);
+        b.t = t;
+        b.id = id | axis | (use_exit ? 4 : 0);
+    }
+}
+
 // Cylinder: the case analysis of shapes.h:231-318 in local space.
 template <class RP> PTD void test_cylinder(RP R, V3 o, V3 d, int id, Best& b) {
     const V3 ol = v3(row_point(R, o), row_point(R + 4, o), row_point(R + 8, o));
@@ -269,6 +290,9 @@ PTD void scan_runs(V3 o, V3 d, float dd, float idd, RP base, KIntP runs, int r0,
             case FP_PLANE_GEN:
                 for (int i = 0; i < run.count; i++, R += 16, id += 8) test_plane_gen(R, o, d, id, b);
                 break;
+            case FP_CUBE_AA:
+                for (int i = 0; i < run.count; i++, R += 6, id += 8) test_cube_box(R, o, inv, id, b);
+                break;
             case FP_PLANE_X:
                 for (int i = 0; i < run.count; i++, R += 5, id += 8) test_plane_axis<0>(R, o, d, inv, id, b);
                 break;
@@ -300,11 +324,13 @@ template <int N> PTD void axis_planes(KFloatP R, int n, V3 o, V3 d, V3 inv, Best
 // loads; a record's scene index << 3 sits right behind it.  Planes go two per trip: one wait covers both records.
 PTD void scan_sorted(V3 o, V3 d, float dd, float idd, const FSorted& S, Best& b) {
     const KFloatP base = as_constant(S.data);
-    if (S.count[FP_PLANE_X] + S.count[FP_PLANE_Y] + S.count[FP_PLANE_Z] > 0) {
+    if (S.count[FP_PLANE_X] + S.count[FP_PLANE_Y] + S.count[FP_PLANE_Z] + S.count[FP_CUBE_AA] > 0) {
         const V3 inv = v3(rcp(d.x), rcp(d.y), rcp(d.z));
         axis_planes<0>(base + S.off[FP_PLANE_X], S.count[FP_PLANE_X], o, d, inv, b);
         axis_planes<1>(base + S.off[FP_PLANE_Y], S.count[FP_PLANE_Y], o, d, inv, b);
         axis_planes<2>(base + S.off[FP_PLANE_Z], S.count[FP_PLANE_Z], o, d, inv, b);
+        KFloatP R = base + S.off[FP_CUBE_AA];
+        for (int i = S.count[FP_CUBE_AA]; i > 0; i--, R += 8) test_cube_box(R, o, inv, __float_as_int(R[6]), b);
     }
     {
         KFloatP R = base + S.off[FP_PLANE];
@@ -377,6 +403,7 @@ PTD void walk_hierarchy(V3 o, V3 d, float dd, float idd, const BNode* __restrict
             switch (q->kind) {
                 case FP_SPHERE_WS: test_sphere_ws(R, o, d, dd, idd, id, b); break;
                 case FP_CUBE: test_cube(R, o, d, id, b); break;
+                case FP_CUBE_AA: test_cube_box(R, o, inv, id, b); break;
                 case FP_SPHERE: test_sphere(R, o, d, id, b); break;
                 default: test_cylinder(R, o, d, id, b); break;
             }
@@ -441,6 +468,7 @@ PTD void walk_fat(V3 o, V3 d, float dd, float idd, const BFat* __restrict__ fat,
         switch (q->kind) {
             case FP_SPHERE_WS: test_sphere_ws(R, o, d, dd, idd, id, b); break;
             case FP_CUBE: test_cube(R, o, d, id, b); break;
+            case FP_CUBE_AA: test_cube_box(R, o, inv, id, b); break;
             case FP_SPHERE: test_sphere(R, o, d, id, b); break;
             default: test_cylinder(R, o, d, id, b); break;
         }
