@@ -41,9 +41,9 @@ def flops_per_sample():
 
 def measured_traffic_bytes(kernel):
     """HBM bytes per launch of the full-frame render kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01/pmc_render_fast_h.json: WRITE_SIZE and FETCH_SIZE in KB, separate passes; FETCH_SIZE doubled
+    (profiles/r01/pmc_render_fast_i.json: WRITE_SIZE and FETCH_SIZE in KB, separate passes; FETCH_SIZE doubled
     as the gfx950 counter reports half the bytes of wide reads).  None when no profile of that kernel is stored."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_render_fast_h.json")
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_render_fast_i.json")
     if kernel != "render_fast_kernel" or not os.path.exists(path):
         return None
     with open(path) as f:
