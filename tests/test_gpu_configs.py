@@ -242,7 +242,7 @@ plane glow     bounds -0.5 -0.5 0.5 0.5  translate 0 -2 -3
             assert not differ[0]
 
 
-def _random_scene_text(rng, n_shapes):
+def _random_scene_text(rng, n_shapes, aligned=False):
     """Shapes of all four types under random rotations, non-uniform scales and translations; shape k glows with
     (k+1, 0.5, 0.25), so the radiance of a depth-0 path names the primitive it hit."""
     lines = []
@@ -255,22 +255,29 @@ def _random_scene_text(rng, n_shapes):
         if kind == "sphere" and k % 8 == 3:
             s[:] = s[0]                                   # uniformly scaled spheres take the world-space test
         t = rng.uniform(-3, 3, 3) + np.array([0, 0, -6.0])
-        opt = "rotate %.6f %.6f %.6f %.6f translate %.5f %.5f %.5f scale %.5f %.5f %.5f" % (rng.uniform(0, 6.28), ax[0], ax[1], ax[2], t[0], t[1], t[2], s[0], s[1], s[2])
+        if aligned:
+            # no rotation, or quarter turns about a world axis (planes then face along x, y or z); mirrored scales
+            s *= rng.choice([-1.0, 1.0], 3)
+            turn = ("", "rotate pi/2 1 0 0 ", "rotate -pi/2 0 1 0 ", "rotate pi 0 1 0 ")[int(rng.integers(0, 4))] if kind == "plane" else ""
+            opt = "%stranslate %.5f %.5f %.5f scale %.5f %.5f %.5f" % (turn, t[0], t[1], t[2], s[0], s[1], s[2])
+        else:
+            opt = "rotate %.6f %.6f %.6f %.6f translate %.5f %.5f %.5f scale %.5f %.5f %.5f" % (rng.uniform(0, 6.28), ax[0], ax[1], ax[2], t[0], t[1], t[2], s[0], s[1], s[2])
         if kind == "plane":
             opt = "bounds -1.2 -0.7 0.9 1.4 " + opt
         lines.append("%s m%d %s" % (kind, k, opt))
     return "\n".join(lines) + "\n"
 
 
-@pytest.mark.parametrize("n_shapes,seed", [(12, 1), (40, 2), (160, 3)])
-def test_fast_hit_decisions_on_random_scenes(oracle, n_shapes, seed):
+@pytest.mark.parametrize("n_shapes,seed,aligned", [(12, 1, False), (40, 2, False), (160, 3, False), (24, 4, True), (120, 5, True)])
+def test_fast_hit_decisions_on_random_scenes(oracle, n_shapes, seed, aligned):
     """Which primitive a ray hits first, fast kernels (loop and hierarchy) against the oracle, on random affine shapes
     and random rays: the parity-order kernels are compared bit by bit elsewhere, this pins the restructured tests of
-    the fast kernels (folded plane bounds, world-space spheres, slab cube, cylinder case analysis)."""
+    the fast kernels (folded plane bounds, world-space spheres, slab cube, cylinder case analysis; with `aligned`, the
+    axis-aligned plane and cube kinds, mirrored scales included)."""
     import torch
     import pathtracer_amd as pt
     rng = np.random.default_rng(seed)
-    prims, n, mats, nm = pt.parse_scene(_random_scene_text(rng, n_shapes), max_prims=n_shapes, max_mats=n_shapes)
+    prims, n, mats, nm = pt.parse_scene(_random_scene_text(rng, n_shapes, aligned), max_prims=n_shapes, max_mats=n_shapes)
     assert n == n_shapes
     N = 20000
     o = (rng.uniform(-4, 4, (N, 3)) + np.array([0, 0, -6.0])).astype(np.float32)
@@ -295,3 +302,12 @@ def test_fast_hit_decisions_on_random_scenes(oracle, n_shapes, seed):
             differ = (rgb != ref).any(axis=1)
             print("random scene %d shapes, bvh_min %s, mode %d: first hit differs for %d of %d rays" % (n_shapes, bvh_min, mode, differ.sum(), N))
             assert differ.mean() <= (0.0 if mode == pt.PT_MATH_PARITY else 1e-3), (bvh_min, mode, int(differ.sum()))
+        # the render kernel's own loops (kind-sorted records, fat hierarchy) on camera rays: at depth 0 a sample's
+        # radiance is the emission of what it hit, so an image pixel differs only if a sample hit something else
+        if "ref_img" not in locals():
+            ref_img = osc.render(oracle.make_config(160, 120, 4, n_bounces=0))
+            assert (ref_img.sum(axis=2) > 0).mean() > 0.2
+        img = sc.render(pt.make_config(160, 120, 4, n_bounces=0, math_mode=pt.PT_MATH_FAST)).cpu().numpy()
+        off = (np.abs(img - ref_img).max(axis=2) > 1e-5).mean()
+        print("random scene %d shapes, bvh_min %s: depth-0 image differs in %.5f of the pixels" % (n_shapes, bvh_min, off))
+        assert off <= 2e-3
