@@ -170,9 +170,10 @@ int bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, float* rec, FSha
                     for (int j = 0; j < 3; j++) rec[4 + 4 * ax + j] = (float)(inv.m[ax][j] * sc[ax]);
                     rec[4 + 4 * ax + 3] = (float)((inv.m[ax][3] - cc[ax]) * sc[ax]);
                 }
-                // A plane whose normal and edges run along world axes (every row above has one entry that matters;
-                // what a rotation by (float)(pi/2) leaves where a zero belongs, ~4e-8 of it, counts as zero) gets the
-                // short test: t = (k - o_n)/d_n, then two interval tests on single coordinates.
+                // A plane whose normal and edges run along world axes (every row above has one entry that matters)
+                // gets the short test: t = (k - o_n)/d_n, then two interval tests on single coordinates.  What a
+                // rotation by (float)(pi/2) or (float)pi leaves where a zero belongs, 4e-8 to 9e-8 of the row, counts
+                // as zero; the limit is 2e-7, the size of a float rounding.
                 int axis[3] = {-1, -1, -1};
                 bool aligned = std::getenv("PT_PLANE_AXIS") == nullptr || std::atoi(std::getenv("PT_PLANE_AXIS")) != 0;
                 for (int r = 0; r < 3 && aligned; r++) {
@@ -180,7 +181,7 @@ int bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, float* rec, FSha
                     int a = 0;
                     for (int j = 1; j < 3; j++) if (fabsf(row[j]) > fabsf(row[a])) a = j;
                     if (row[a] == 0.0f) { if (r == 0) aligned = false; continue; }   // an unbounded edge direction: no entry at all
-                    for (int j = 0; j < 3; j++) if (j != a && fabsf(row[j]) > 1e-6f * fabsf(row[a])) aligned = false;
+                    for (int j = 0; j < 3; j++) if (j != a && fabsf(row[j]) > 2e-7f * fabsf(row[a])) aligned = false;
                     axis[r] = a;
                 }
                 if (aligned) {
@@ -233,12 +234,12 @@ int bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, float* rec, FSha
         }
         case PT_CUBE: {
             for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) fs->a[j * 3 + i] = ncol[j][i];
-            // Diagonal L (off-diagonal entries below 1e-6 of their column's diagonal entry): the cube is a box along
+            // Diagonal L (off-diagonal entries below 2e-7 of their column's diagonal entry): the cube is a box along
             // the world axes and is tested there, local axis i being world axis i.
             bool diagonal = std::getenv("PT_CUBE_AXIS") == nullptr || std::atoi(std::getenv("PT_CUBE_AXIS")) != 0;
             for (int j = 0; j < 3 && diagonal; j++) {
                 if (fwd.m[j][j] == 0.0f) diagonal = false;
-                for (int i = 0; i < 3; i++) if (i != j && fabsf(fwd.m[i][j]) > 1e-6f * fabsf(fwd.m[j][j])) diagonal = false;
+                for (int i = 0; i < 3; i++) if (i != j && fabsf(fwd.m[i][j]) > 2e-7f * fabsf(fwd.m[j][j])) diagonal = false;
             }
             if (diagonal) {
                 *ftype = FP_CUBE_AA;
