@@ -115,10 +115,14 @@ def main():
     # rank r renders rows r, r+N, ... into a compact tile; all-gather + strided copy rebuild the image
     part = emulate or world              # ranks the frame is split over
     my_rows = len(multigpu.rank_rows(HEIGHT, rank, part))
-    cfg = pt.make_config(WIDTH, HEIGHT, SPP, n_bounces=DEPTH, seed=SEED, row_begin=rank, row_end=HEIGHT, row_step=part,
-                         fb_compact=1, math_mode=math_mode)
     # PT_BENCH_FORCE_OVERLAP=1 exercises the pipeline on one GPU (development aid)
     overlap = (part > 1 or os.environ.get("PT_BENCH_FORCE_OVERLAP") == "1") and not args.no_overlap
+    # Launches in flight on alternating streams fill each other's tails, so large tiles (less drain per wave) pay:
+    # measured per rank share of this frame, 64 pixels per wave from 0.4 Mpixel, 32 below (the library's own choice,
+    # 16 or 8 pixels, suits a launch that has the GPU to itself).  The image does not depend on the tile size.
+    tile_log2 = (6 if my_rows * WIDTH >= 400000 else 5) if overlap else 0
+    cfg = pt.make_config(WIDTH, HEIGHT, SPP, n_bounces=DEPTH, seed=SEED, row_begin=rank, row_end=HEIGHT, row_step=part,
+                         fb_compact=1, math_mode=math_mode, tile_log2=tile_log2)
     frames = [multigpu.TiledFrame(HEIGHT, WIDTH, part, device, collective=not emulate) for _ in range(2 if overlap else 1)]
     main_stream = torch.cuda.current_stream()
     comm_stream = torch.cuda.Stream(device=device) if overlap else None

@@ -325,6 +325,7 @@ struct render_options {
     int fb_compact = 0;          // 1: the k-th rendered row is written as row k of fb
     int math_mode = PT_MATH_FAST;
     int bsdf_model = PT_BSDF_REFERENCE;   // PT_BSDF_CLASSES: tracePath of bsdf_alternative.h
+    int tile_log2 = 0;           // log2 of the pixels per wave64 (2..6), 0 = chosen from the launch size
     int device = 0;
 };
 
@@ -337,7 +338,7 @@ inline pt_config pt_make_config(const config_t& config, const render_options& op
     c.n_samples = opt.n_samples; c.n_bounces = opt.n_bounces; c.seed = opt.seed;
     c.row_begin = opt.row_begin; c.row_end = opt.row_end < 0 ? config.max_y : opt.row_end;
     c.fb_layout = PT_FB_AOS; c.math_mode = opt.math_mode;
-    c.row_step = opt.row_step; c.fb_compact = opt.fb_compact; c.bsdf_model = opt.bsdf_model;
+    c.row_step = opt.row_step; c.fb_compact = opt.fb_compact; c.bsdf_model = opt.bsdf_model; c.tile_log2 = opt.tile_log2;
     return c;
 }
 

@@ -76,7 +76,11 @@ enum {
  * (row 0 = bottom of the image, main.cu:38; row_step 0 means 1).  With
  * fb_compact = 0 a rendered row is written at its place in the full framebuffer;
  * with fb_compact = 1 the k-th rendered row is written as row k of d_fb, which
- * then only needs room for the rendered rows (interleaved multi-GPU tiles). */
+ * then only needs room for the rendered rows (interleaved multi-GPU tiles).
+ * tile_log2: log2 of the pixels one wave64 renders (2..6), 0 = chosen from the
+ * launch size.  The image does not depend on it.  The automatic choice suits a
+ * launch that has the GPU to itself; a host that keeps several launches in flight
+ * on different streams (they fill each other's tails) does better with 5 or 6. */
 typedef struct pt_config {
     float camera_pos[3];
     int32_t max_x;
@@ -93,6 +97,7 @@ typedef struct pt_config {
     int32_t row_step;
     int32_t fb_compact;
     int32_t bsdf_model;
+    int32_t tile_log2;
 } pt_config;
 
 typedef struct pt_scene pt_scene; /* opaque; owns the device copy of the primitive table */

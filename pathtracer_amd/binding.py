@@ -39,7 +39,7 @@ class pt_config(C.Structure):
         ("focal_length", C.c_float), ("view_port_height", C.c_float),
         ("n_samples", C.c_int32), ("n_bounces", C.c_int32), ("seed", C.c_uint32),
         ("row_begin", C.c_int32), ("row_end", C.c_int32), ("fb_layout", C.c_int32), ("math_mode", C.c_int32),
-        ("row_step", C.c_int32), ("fb_compact", C.c_int32), ("bsdf_model", C.c_int32),
+        ("row_step", C.c_int32), ("fb_compact", C.c_int32), ("bsdf_model", C.c_int32), ("tile_log2", C.c_int32),
     ]
 
 
@@ -138,7 +138,7 @@ def synthetic_scene(n_spheres, n_cubes, seed=12345):
 
 
 def make_config(width, height, spp, n_bounces=5, seed=0, row_begin=0, row_end=None, camera=(0.0, 0.0, 0.0),
-                fb_layout=PT_FB_AOS, math_mode=PT_MATH_FAST, row_step=1, fb_compact=0, bsdf_model=PT_BSDF_REFERENCE):
+                fb_layout=PT_FB_AOS, math_mode=PT_MATH_FAST, row_step=1, fb_compact=0, bsdf_model=PT_BSDF_REFERENCE, tile_log2=0):
     """config_t of main.cu:234 with the reference's camera (origin, v_height 5, fov 45)."""
     cfg = pt_config()
     cfg.camera_pos[:] = camera
@@ -151,6 +151,7 @@ def make_config(width, height, spp, n_bounces=5, seed=0, row_begin=0, row_end=No
     cfg.fb_layout, cfg.math_mode = fb_layout, math_mode
     cfg.row_step, cfg.fb_compact = row_step, fb_compact
     cfg.bsdf_model = bsdf_model
+    cfg.tile_log2 = tile_log2
     return cfg
 
 

@@ -624,6 +624,7 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     if (cfg->row_step < 0) return PT_FAIL("pt_render: negative row_step");
     if (cfg->fb_compact != 0 && cfg->fb_compact != 1) return PT_FAIL("pt_render: fb_compact must be 0 or 1");
     if (cfg->bsdf_model != PT_BSDF_REFERENCE && cfg->bsdf_model != PT_BSDF_CLASSES) return PT_FAIL("pt_render: unknown bsdf_model");
+    if (cfg->tile_log2 != 0 && (cfg->tile_log2 < 2 || cfg->tile_log2 > 6)) return PT_FAIL("pt_render: tile_log2 must be 0 or 2..6");
     PT_CHECK(hipSetDevice(sc->device));
     RenderArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -659,6 +660,7 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     // primitives, 1080p, 4 spp: 263 ms with 32 pixels per wave, 216 ms with 64) — as long as that leaves two waves
     // for every wave slot of the chip.
     while (a.tile_log2 < 6 && ((uint32_t)cfg->n_samples << a.tile_log2) < 2048u && (a.n_lin >> (a.tile_log2 + 1)) >= 16384u) a.tile_log2++;
+    if (cfg->tile_log2 != 0) a.tile_log2 = cfg->tile_log2;
     if (const char* e = std::getenv("PT_TILE_LOG2")) { const int v = std::atoi(e); if (v >= 2 && v <= 6) a.tile_log2 = v; }
     a.fb_layout = cfg->fb_layout;
     a.n_prims = sc->n_prims; a.n_mats = sc->n_mats;

@@ -30,7 +30,7 @@ def test_struct_layouts_match_the_reference_sizes():
     from pathtracer_amd import binding
     assert C.sizeof(binding.pt_material) == 72          # materials.h: 17 floats + int
     assert C.sizeof(binding.pt_prim) == 72
-    assert C.sizeof(binding.pt_config) == 68
+    assert C.sizeof(binding.pt_config) == 72
 
 
 def test_default_scene_builder_matches_oracle_bitwise(oracle):

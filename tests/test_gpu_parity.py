@@ -211,13 +211,11 @@ def test_render_is_deterministic_and_tiling_independent(torch, pt):
                 assert comp.shape[0] == len(range(r, 120, parts))
                 assert torch.equal(comp, a[r::parts]), (mm, parts, "compact")
         # pixels per wave (4 .. 64) do not change a single bit: pixel sums are exact integer sums
-        import os
-        try:
-            for lg in ("2", "3", "4", "5", "6"):
-                os.environ["PT_TILE_LOG2"] = lg
-                assert torch.equal(sc.render(cfg), a), (mm, lg)
-        finally:
-            os.environ.pop("PT_TILE_LOG2", None)
+        for lg in (2, 3, 4, 5, 6):
+            assert torch.equal(sc.render(pt.make_config(200, 120, 8, math_mode=mm, tile_log2=lg)), a), (mm, lg)
+        for bad in (1, 7, -3):
+            with pytest.raises(pt.PtError):
+                sc.render(pt.make_config(200, 120, 8, math_mode=mm, tile_log2=bad))
 
 
 def test_render_edge_cases(torch, pt, oracle):
