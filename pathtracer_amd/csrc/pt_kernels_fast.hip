@@ -2,13 +2,17 @@
 //
 // Same algorithm, same counter-RNG streams and same branch structure as the
 // parity-order kernels, but written for VALU throughput:
-//  * the primitive loop walks runs of same-kind primitives and reads their
-//    records through scalar loads (every index is wave-uniform), so the records
-//    live in SGPRs and cost no VGPRs and no LDS bandwidth;
+//  * primitive records are read through scalar loads (every index is
+//    wave-uniform), so they live in SGPRs and cost no VGPRs and no LDS bandwidth;
+//    PT_MATH_FAST reads them sorted by kind, one typed loop per kind, which the
+//    order-free (distance, index) rule of the tests allows; the other variants
+//    walk runs of same-kind primitives in scene order;
 //  * planes are tested as t = -(n.o + w) / (n.d) with the bounds check on two
-//    more rows of T^-1; uniformly scaled spheres are tested in world space;
-//    cubes keep the slab test and remember the face axis so the normal needs no
-//    second transform;
+//    more rows of T^-1, planes and cubes along the world axes by coordinates;
+//    uniformly scaled spheres are tested in world space; cubes keep the slab
+//    test and remember the face axis so the normal needs no second transform;
+//  * scenes with many finite primitives are searched through a bounding-volume
+//    hierarchy (per-lane walk, stack in LDS);
 //  * the hit position is o + d*t in world space; normals come from a per-
 //    primitive shading record gathered from LDS for the winner only;
 //  * v_rcp/v_rsq/v_sqrt/v_exp and v_sin/v_cos (which take revolutions, so the
