@@ -208,6 +208,19 @@ int pt_comm_world(const pt_comm* comm);
  * communicator's device, ordered on `stream`; every rank must call it. */
 int pt_gather_framebuffer(pt_comm* comm, const float* d_tile, float* d_gathered, float* d_full,
                           int height, int width, void* stream);
+/* pt_gather_framebuffer for callers that cannot allocate or bring a workspace
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  No counterpart in the reference.  The gathered tiles are staged
+ * in a static device array inside the library instead of d_gathered, so the
+ * call itself allocates nothing; the array's per-device address is resolved
+ * when the communicator is made (pt_comm_init_rank / pt_comm_init_all).
+ * Limit: world x pt_tile_rows(height, world) x width x 3 floats must not exceed
+ * PT_GATHER_NOALLOC_MAX_FLOATS (32 MiB: a 1920x1080 frame for any world <= 8);
+ * larger frames are refused with an error and need pt_gather_framebuffer.
+ * All calls on one GPU share that GPU's array: calls that overlap in time on
+ * one GPU (different streams or communicators) race; order them. */
+#define PT_GATHER_NOALLOC_MAX_FLOATS (8u << 20)
+int pt_gather_framebuffer_noalloc(pt_comm* comm, const float* d_tile, float* d_full, int height, int width, void* stream);
 /* The reordering step alone: gathered[r][k] -> image row k*world + r, launched on
  * `stream` (the null stream: the calling thread's current device). */
 int pt_assemble_rows(const float* d_gathered, float* d_full, int height, int width, int world, void* stream);

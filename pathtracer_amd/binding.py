@@ -87,6 +87,7 @@ def _load():
     L.pt_comm_world.argtypes = [vp]
     L.pt_gather_framebuffer.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.pt_assemble_rows.argtypes = [vp, vp, i32, i32, i32, vp]
+    L.pt_gather_framebuffer_noalloc.argtypes = [vp, vp, vp, i32, i32, vp]
     return L
 
 
@@ -98,7 +99,7 @@ EXPORTS = [
     "pt_trace_paths", "pt_trace_paths_alt", "pt_rng_draws", "pt_ppm_p3", "pt_last_error", "pt_version",
     "pt_scene_parse", "pt_ppm_p6", "pt_pfm",
     "pt_tile_rows", "pt_comm_unique_id", "pt_comm_init_rank", "pt_comm_init_all", "pt_comm_free", "pt_comm_rank",
-    "pt_comm_world", "pt_gather_framebuffer", "pt_assemble_rows",
+    "pt_comm_world", "pt_gather_framebuffer", "pt_assemble_rows", "pt_gather_framebuffer_noalloc",
 ]
 
 
@@ -353,4 +354,14 @@ class Comm:
         assert full.numel() >= height * width * 3
         with _torch().cuda.device(self.device):
             _check(lib.pt_gather_framebuffer(self.h, _ptr(tile), _ptr(gathered), _ptr(full), height, width, _stream()))
+        return full
+
+    def gather_noalloc(self, tile, full, height, width):
+        """pt_gather_framebuffer_noalloc: the same gather staged in the library's static device array (at most
+        32 MiB of gathered tiles); allocates nothing.  Calls that overlap in time on one GPU race."""
+        rows = lib.pt_tile_rows(height, self.world)
+        assert tile.is_contiguous() and full.is_contiguous()
+        assert tile.numel() >= rows * width * 3 and full.numel() >= height * width * 3
+        with _torch().cuda.device(self.device):
+            _check(lib.pt_gather_framebuffer_noalloc(self.h, _ptr(tile), _ptr(full), height, width, _stream()))
         return full

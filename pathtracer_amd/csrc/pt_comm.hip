@@ -82,11 +82,29 @@ __global__ __launch_bounds__(256) void assemble_rows_kernel(const float* __restr
     }
 }
 
+// Staging area of pt_gather_framebuffer_noalloc: the gathered tiles of one frame, world x pt_tile_rows x width x 3
+// floats, at most PT_GATHER_NOALLOC_MAX_FLOATS (32 MiB: a 1920x1080 frame over any world size up to 8).  Every GPU
+// the library's code object is loaded on holds its own copy until the process ends.  In host code the array's name is
+// only a handle for hipGetSymbolAddress; the address that call returns, kept per communicator, is what the all-gather
+// and the reordering kernel are given.
+static __device__ __align__(256) float scratch[PT_GATHER_NOALLOC_MAX_FLOATS];
+
+// Device address of `scratch` on the CURRENT device (each GPU has its own).  Called from the communicator set-up
+// calls, never from the gather itself: the first use of a code object on a device may load it, which allocates.
+int scratch_address(float** out) {
+    void* p = nullptr;
+    PT_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return PT_FAIL("hipGetSymbolAddress(scratch) returned a null address");
+    *out = static_cast<float*>(p);
+    return 0;
+}
+
 }  // namespace
 
 struct pt_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
+    float* scratch = nullptr;   // this device's copy of the static staging array
 };
 
 extern "C" {
@@ -114,6 +132,7 @@ int pt_comm_init_rank(const char* id, int rank, int world, int device, pt_comm**
     pt_comm* c = new (std::nothrow) pt_comm;
     if (!c) return PT_FAIL("pt_comm_init_rank: out of host memory");
     c->rank = rank; c->world = world; c->device = device;
+    if (const int rc = scratch_address(&c->scratch)) { delete c; return rc; }
     const ncclResult_t r = R->CommInitRank(&c->comm, world, u, rank);
     if (r != ncclSuccess) { delete c; return rccl_error(r, "ncclCommInitRank", __FILE__, __LINE__); }
     *out = c;
@@ -136,6 +155,19 @@ int pt_comm_init_all(int world, const int* devices, pt_comm** out) {
         c->comm = comms[(size_t)r]; c->rank = r; c->world = world; c->device = devices[r];
         out[r] = c;
     }
+    // each device's own address of the static staging array, resolved with that device current
+    int before = 0;
+    PT_CHECK(hipGetDevice(&before));
+    for (int r = 0; r < world; r++) {
+        hipError_t e = hipSetDevice(devices[r]);
+        int rc = e == hipSuccess ? scratch_address(&out[r]->scratch) : pt_set_error((int)e, "hipSetDevice(devices[r])", __FILE__, __LINE__);
+        if (rc) {
+            for (int k = 0; k < world; k++) { (void)R->CommDestroy(comms[(size_t)k]); delete out[k]; out[k] = nullptr; }
+            (void)hipSetDevice(before);
+            return rc;
+        }
+    }
+    PT_CHECK(hipSetDevice(before));
     return 0;
 }
 
@@ -176,6 +208,24 @@ int pt_gather_framebuffer(pt_comm* c, const float* d_tile, float* d_gathered, fl
     const size_t tile_floats = (size_t)pt_tile_rows(height, c->world) * (size_t)width * 3u;
     PT_RCCL(g_rccl.AllGather(d_tile, d_gathered, tile_floats, ncclFloat, c->comm, (hipStream_t)stream));
     return pt_assemble_rows(d_gathered, d_full, height, width, c->world, stream);
+}
+
+int pt_gather_framebuffer_noalloc(pt_comm* c, const float* d_tile, float* d_full, int height, int width, void* stream) {
+    if (!c || !d_tile || !d_full || height <= 0 || width <= 0) return PT_FAIL("pt_gather_framebuffer_noalloc: bad arguments");
+    if (!g_rccl.ok) return PT_FAIL("pt_gather_framebuffer_noalloc: librccl.so.1 could not be loaded");
+    if (!c->scratch) return PT_FAIL("pt_gather_framebuffer_noalloc: the communicator holds no staging address");
+    const size_t tile_floats = (size_t)pt_tile_rows(height, c->world) * (size_t)width * 3u;
+    if (tile_floats * (size_t)c->world > (size_t)PT_GATHER_NOALLOC_MAX_FLOATS) {
+        static thread_local char text[200];
+        std::snprintf(text, sizeof(text), "pt_gather_framebuffer_noalloc: %zu gathered floats exceed the static staging area of %zu (PT_GATHER_NOALLOC_MAX_FLOATS); use pt_gather_framebuffer",
+                      tile_floats * (size_t)c->world, (size_t)PT_GATHER_NOALLOC_MAX_FLOATS);
+        return PT_FAIL(text);
+    }
+    PT_CHECK(hipSetDevice(c->device));
+    // Every float of the staging area that the reordering reads is written by the all-gather first, so nothing
+    // has to be cleared between calls.
+    PT_RCCL(g_rccl.AllGather(d_tile, c->scratch, tile_floats, ncclFloat, c->comm, (hipStream_t)stream));
+    return pt_assemble_rows(c->scratch, d_full, height, width, c->world, stream);
 }
 
 }  // extern "C"
