@@ -12,6 +12,10 @@ that frame k's last waves leave idle), so total work is fixed: "strong" scaling.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+Started without a launcher (`python bench.py --gpus N`, no WORLD_SIZE in the environment) with N > 1, this process
+starts the N ranks itself as fresh child processes before it touches the GPU, relays rank 0's line and exits non-zero
+if any rank does.
+
 Rank 0 prints one JSON line.  `roofline` prices the render kernel against the
 FP32 vector peak with ALGORITHMIC flops (the event table in
 oracle/pt_oracle.hpp, counted per config by tools/count_flops.py into
@@ -21,7 +25,10 @@ host on a bounded sample of the same frame.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -78,6 +85,50 @@ def cpu_baseline(gpu_image):
     return base, parity
 
 
+def launch_ranks(n, command, extra_env=None, out=None):
+    """Starts `command` n times as child processes, one per rank (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR,
+    MASTER_PORT set as torch.distributed.run sets them), waits for all, writes rank 0's standard output to `out`
+    (default: this process's) and returns 0 if every rank exited 0, else the first non-zero exit status (a rank
+    killed by signal s counts as 128 + s).  When a rank fails, the ranks still running are ended (they would wait
+    in a collective forever).  The caller must not have initialised the GPU: the children are fresh processes, this
+    one only waits."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen(command, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    status = 0
+    pending = set(range(n))
+    rank0_out = b""
+
+    def drain():
+        nonlocal rank0_out
+        rank0_out = procs[0].stdout.read()
+    t = threading.Thread(target=drain, daemon=True)
+    t.start()
+    while pending:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 128 - rc
+                for q in pending:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    t.join(timeout=10)
+    (out or sys.stdout.buffer).write(rank0_out)
+    (out or sys.stdout.buffer).flush()
+    return status
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +140,10 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="development aid on one GPU: render rank 0's share of an N-GPU run with the N-GPU pipeline, no collectives")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: be one.  Nothing above has touched the GPU (torch is not even imported yet).
+        raise SystemExit(launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -179,10 +234,38 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     image = frames[(args.warmup + args.steps - 1) % len(frames)].image
 
-    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)
+    # One frame at a time (render, then gather, nothing in flight beside it): what a single frame costs end to end.
+    single_ms = None
+    bitwise = None
+    if part > 1:
+        n_single = max(1, min(args.steps, 10))
+        f0 = frames[0]
+        cfg_single = pt.make_config(WIDTH, HEIGHT, SPP, n_bounces=DEPTH, seed=SEED, row_begin=rank, row_end=HEIGHT, row_step=part,
+                                    fb_compact=1, math_mode=math_mode)      # tile size: the library's choice for a lone launch
+        fence()
+        ts = time.perf_counter()
+        for _ in range(n_single):
+            if my_rows:
+                scene.render(cfg_single, out=f0.local)
+            f0.gather()
+            torch.cuda.synchronize()
+        fence()
+        single_ms = (time.perf_counter() - ts) / n_single * 1e3
+    if world > 1:
+        # Rank 0 renders the whole frame alone (untimed) and compares the gathered image with it, bit for bit.
+        flag = torch.ones(1, dtype=torch.int32, device=device)
+        if rank == 0:
+            alone = scene.render(pt.make_config(WIDTH, HEIGHT, SPP, n_bounces=DEPTH, seed=SEED, math_mode=math_mode))
+            flag[0] = 1 if torch.equal(alone, image) else 0
+        dist.broadcast(flag, src=0)
+        bitwise = bool(int(flag[0]))
+
+    t = torch.tensor([elapsed, kernel_ms, single_ms or 0.0], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = float(t[0]), float(t[1])
+    if single_ms is not None:
+        single_ms = float(t[2])
 
     if rank == 0:
         total_samples = WIDTH * HEIGHT * SPP
@@ -208,11 +291,18 @@ def main():
             "roofline": {"bound": "valu_fp32", "kernel": {"fast": "render_fast_kernel", "scalar": "render_fast_kernel", "lds": "render_fast_tiled_kernel", "parity": "render_parity_kernel"}[args.math],
                          "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VALU_PEAK_TFLOPS,
-                         "traffic": measured_traffic_bytes("render_fast_kernel" if args.math in ("fast", "scalar") else args.math) if world == 1 else None,
+                         "traffic": measured_traffic_bytes("render_fast_kernel" if args.math == "fast" else args.math) if world == 1 and not emulate else None,
                          "kernel_ms": kernel_ms, "kernel_msamples_per_s": tile_samples / launch_ms / 1e3,
                          "launches_overlap": bool(overlap)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if part > 1:
+            # the rate above is a pipeline rate: frames_in_flight frames render and gather concurrently; the time of
+            # one frame rendered and gathered on its own is given beside it
+            out["pipelined"] = bool(overlap)
+            out["frames_in_flight"] = len(frames)
+            out["single_frame_ms"] = single_ms
+            out["bitwise_equal_to_single_gpu"] = bitwise
+        if world == 1 and not emulate and not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity_vs_oracle"] = cpu_baseline(image)
         print(json.dumps(out), flush=True)
     if world > 1:
