@@ -105,7 +105,32 @@ typedef struct pt_scene pt_scene; /* opaque; owns the device copy of the primiti
 /* Replaces cudaMalloc + constructScene<<<1,1>>> (main.cu:213-220): flattens the
  * shapes into the device primitive table on `device`. */
 int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, int n_mats, int device, pt_scene** out);
+/* The same with explicit build options (NULL = the defaults, which is what pt_scene_upload uses).  No counterpart
+ * in the reference.  They change how PT_MATH_FAST searches the scene, never which hit it finds. */
+typedef struct pt_upload_options {
+    int32_t bvh_min_prims;  /* finite primitives (spheres, cubes, cylinders) from which PT_MATH_FAST builds a
+                             * bounding-volume hierarchy; 0 = the default (96), values >= 2 */
+    int32_t bvh_leaf_prims; /* primitives per leaf, 1..15; 0 = the default (1) */
+    int32_t general_kinds;  /* non-zero: planes and cubes along the world axes keep the general record kinds
+                             * (the tests a rotated scene gets) */
+} pt_upload_options;
+int pt_scene_upload_opt(const pt_prim* prims, int n_prims, const pt_material* mats, int n_mats, int device,
+                        const pt_upload_options* opt, pt_scene** out);
 int pt_scene_free(pt_scene* scene);
+/* Launch parameters of pt_render for this scene, by knob; the image never depends on them.  value 0 = the library's
+ * own (measured) choice.  No counterpart in the reference.  Not to be called while a pt_render call on the same
+ * scene runs in another thread. */
+enum {
+    PT_TUNE_TILE_LOG2 = 0,   /* log2 of the pixels per wave (2..6) when pt_config.tile_log2 is 0 */
+    PT_TUNE_WALK_BUDGET = 1, /* hierarchy nodes a lane visits per loop iteration (>= 1) */
+    PT_TUNE_SHADE_GATE = 2,  /* lanes whose hierarchy search is over before they are shaded together (1..64) */
+    PT_TUNE_BVH_WALK = 3,    /* 1: walk the hierarchy in its skip-link form instead of the two-children-per-node form */
+    PT_TUNE_GLASS_QUEUE = 4, /* PT_MATH_FAST, no hierarchy: entries per wave of the LDS queue in which hits on glass
+                              * wait to be shaded together (8..64); -1: no queue, every hit is shaded where it is found */
+    PT_TUNE_GLASS_GATE = 5,  /* queue entries from which free lanes take them back (1..queue size) */
+    PT_TUNE_COUNT = 6
+};
+int pt_scene_tune(pt_scene* scene, int knob, int value);
 int pt_scene_device(const pt_scene* scene);
 /* Nodes of the scene's bounding-volume hierarchy (0 = the scene has none: every
  * primitive is tested for every ray).  No counterpart in the reference, whose

@@ -43,6 +43,13 @@ class pt_config(C.Structure):
     ]
 
 
+class pt_upload_options(C.Structure):
+    _fields_ = [("bvh_min_prims", C.c_int32), ("bvh_leaf_prims", C.c_int32), ("general_kinds", C.c_int32)]
+
+
+PT_TUNE_TILE_LOG2, PT_TUNE_WALK_BUDGET, PT_TUNE_SHADE_GATE, PT_TUNE_BVH_WALK, PT_TUNE_GLASS_QUEUE, PT_TUNE_GLASS_GATE = range(6)
+
+
 class PtError(RuntimeError):
     pass
 
@@ -62,6 +69,8 @@ def _load():
     L.pt_glass_grid_scene.argtypes = [i32, C.POINTER(pt_prim), C.POINTER(pt_material), C.POINTER(i32)]
     L.pt_synthetic_scene.argtypes = [i32, i32, u32, C.POINTER(pt_prim), C.POINTER(pt_material), C.POINTER(i32)]
     L.pt_scene_upload.argtypes = [C.POINTER(pt_prim), i32, C.POINTER(pt_material), i32, i32, C.POINTER(vp)]
+    L.pt_scene_upload_opt.argtypes = [C.POINTER(pt_prim), i32, C.POINTER(pt_material), i32, i32, C.POINTER(pt_upload_options), C.POINTER(vp)]
+    L.pt_scene_tune.argtypes = [vp, i32, i32]
     L.pt_scene_free.argtypes = [vp]
     L.pt_scene_device.argtypes = [vp]
     L.pt_scene_bvh_nodes.argtypes = [vp]
@@ -94,7 +103,7 @@ def _load():
 lib = _load()
 
 EXPORTS = [
-    "pt_scene_upload", "pt_scene_free", "pt_scene_device", "pt_scene_bvh_nodes", "pt_default_scene", "pt_glass_grid_scene",
+    "pt_scene_upload", "pt_scene_upload_opt", "pt_scene_tune", "pt_scene_free", "pt_scene_device", "pt_scene_bvh_nodes", "pt_default_scene", "pt_glass_grid_scene",
     "pt_synthetic_scene", "pt_focal_length", "pt_render", "pt_raypath_batch", "pt_nearest_batch",
     "pt_trace_paths", "pt_trace_paths_alt", "pt_rng_draws", "pt_ppm_p3", "pt_last_error", "pt_version",
     "pt_scene_parse", "pt_ppm_p6", "pt_pfm",
@@ -225,11 +234,21 @@ def _ptr(t):
 class Scene:
     """Device copy of a scene (pt_scene_upload / pt_scene_free)."""
 
-    def __init__(self, prims, n, mats, n_mats, device=0):
+    def __init__(self, prims, n, mats, n_mats, device=0, bvh_min_prims=0, bvh_leaf_prims=0, general_kinds=False):
+        """The keyword options are pt_upload_options (0 / False = the library's defaults)."""
         self.n, self.n_mats, self.device = n, n_mats, device
         h = C.c_void_p(0)
-        _check(lib.pt_scene_upload(prims, n, mats, n_mats, device, C.byref(h)))
+        if bvh_min_prims or bvh_leaf_prims or general_kinds:
+            opt = pt_upload_options(bvh_min_prims, bvh_leaf_prims, 1 if general_kinds else 0)
+            _check(lib.pt_scene_upload_opt(prims, n, mats, n_mats, device, C.byref(opt), C.byref(h)))
+        else:
+            _check(lib.pt_scene_upload(prims, n, mats, n_mats, device, C.byref(h)))
         self.h = h
+
+    def tune(self, knob, value):
+        """pt_scene_tune: a launch parameter of this scene's renders (PT_TUNE_*; 0 = the library's choice)."""
+        _check(lib.pt_scene_tune(self.h, knob, value))
+        return self
 
     def close(self):
         if getattr(self, "h", None):

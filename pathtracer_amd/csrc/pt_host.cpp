@@ -133,7 +133,7 @@ float len3(float x, float y, float z) { return sqrtf(x * x + y * y + z * z); }
 
 // Kind, intersection record and shading record of the fast kernels for one
 // shape.  Returns the record length in floats.
-int bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, float* rec, FShade* fs, int32_t* ftype) {
+int bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, bool axis_kinds, float* rec, FShade* fs, int32_t* ftype) {
     std::memset(fs, 0, sizeof(*fs));
     fs->type = p.type; fs->material = p.material;
     // Columns of L and the unit normals along them.  The reference forms a normal as normalize(T*axis - wOrigin)
@@ -175,7 +175,7 @@ int bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, float* rec, FSha
                 // rotation by (float)(pi/2) or (float)pi leaves where a zero belongs, 4e-8 to 9e-8 of the row, counts
                 // as zero; the limit is 2e-7, the size of a float rounding.
                 int axis[3] = {-1, -1, -1};
-                bool aligned = std::getenv("PT_PLANE_AXIS") == nullptr || std::atoi(std::getenv("PT_PLANE_AXIS")) != 0;
+                bool aligned = axis_kinds;
                 for (int r = 0; r < 3 && aligned; r++) {
                     const float* row = rec + 4 * r;
                     int a = 0;
@@ -236,7 +236,7 @@ int bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, float* rec, FSha
             for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) fs->a[j * 3 + i] = ncol[j][i];
             // Diagonal L (off-diagonal entries below 2e-7 of their column's diagonal entry): the cube is a box along
             // the world axes and is tested there, local axis i being world axis i.
-            bool diagonal = std::getenv("PT_CUBE_AXIS") == nullptr || std::atoi(std::getenv("PT_CUBE_AXIS")) != 0;
+            bool diagonal = axis_kinds;
             for (int j = 0; j < 3 && diagonal; j++) {
                 if (fwd.m[j][j] == 0.0f) diagonal = false;
                 for (int i = 0; i < 3; i++) if (i != j && fabsf(fwd.m[i][j]) > 2e-7f * fabsf(fwd.m[j][j])) diagonal = false;
@@ -282,6 +282,23 @@ void world_box(const pt_prim& p, const Aff& fwd, float* lo, float* hi) {
     }
 }
 
+// World-space box of a plane's rectangle (shapes.h:105-112): the corners (xMin|xMax, yMin|yMax, 0) under T.  A
+// rectangle without an edge on some side (bounds beyond +-1e30) gets an infinite box.
+void plane_box(const pt_prim& p, const Aff& fwd, float* lo, float* hi) {
+    bool finite = true;
+    for (int j = 0; j < 4; j++) finite = finite && fabsf(p.bounds[j]) <= 1e30f;
+    for (int i = 0; i < 3; i++) { lo[i] = finite ? INFINITY : -INFINITY; hi[i] = finite ? -INFINITY : INFINITY; }
+    if (!finite) return;
+    for (int cx = 0; cx < 2; cx++)
+        for (int cy = 0; cy < 2; cy++) {
+            const float x = p.bounds[cx ? 2 : 0], y = p.bounds[cy ? 3 : 1];
+            for (int i = 0; i < 3; i++) {
+                const float w = fwd.m[i][0] * x + fwd.m[i][1] * y + fwd.m[i][3];
+                lo[i] = fminf(lo[i], w); hi[i] = fmaxf(hi[i], w);
+            }
+        }
+}
+
 // Packs the records of primitives `ids` (ascending scene indices) into one float array cut into runs of
 // consecutive same-kind primitives.  Runs start on a 64-byte line; a record never straddles a chunk boundary and a
 // run never spans two chunks.  Returns the number of chunks.
@@ -320,7 +337,8 @@ int pack_runs(const std::vector<Baked>& baked, const std::vector<int>& ids, std:
 // Packs the records of primitives `ids` (ascending scene indices) sorted by kind, each with its scene index << 3
 // behind it (as int bits), at the kind's stride.  Offsets are 16-float aligned; 32 floats of padding follow the last
 // record because the loops fetch records two at a time.
-void pack_sorted(const std::vector<Baked>& baked, const std::vector<int>& ids, std::vector<float>& data, FSorted& hdr) {
+void pack_sorted(const std::vector<Baked>& baked, const std::vector<int>& ids, std::vector<float>& data, FSorted& hdr,
+                 std::vector<float>* boxes = nullptr) {
     std::memset(&hdr, 0, sizeof(hdr));
     for (int kind = 0; kind < FP_KINDS; kind++) {
         data.resize((data.size() + 15) / 16 * 16, 0.0f);
@@ -335,6 +353,11 @@ void pack_sorted(const std::vector<Baked>& baked, const std::vector<int>& ids, s
             const int32_t id = (int32_t)(k << 3);
             std::memcpy(&data[at + (size_t)b.len], &id, sizeof(id));
             hdr.count[kind]++;
+            if (boxes) {
+                // padded like the hierarchy's boxes: the culling test's rounding must never drop a record its own test accepts
+                for (int i = 0; i < 3; i++) boxes->push_back(b.lo[i] - 1e-4f * (1.0f + fabsf(b.lo[i])));
+                for (int i = 0; i < 3; i++) boxes->push_back(b.hi[i] + 1e-4f * (1.0f + fabsf(b.hi[i])));
+            }
         }
     }
     data.resize(data.size() + 32, 0.0f);
@@ -498,7 +521,16 @@ int pt_synthetic_scene(int n_spheres, int n_cubes, uint32_t seed, pt_prim* prims
 }
 
 int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, int n_mats, int device, pt_scene** out) {
+    return pt_scene_upload_opt(prims, n_prims, mats, n_mats, device, nullptr, out);
+}
+
+int pt_scene_upload_opt(const pt_prim* prims, int n_prims, const pt_material* mats, int n_mats, int device,
+                        const pt_upload_options* opt, pt_scene** out) {
     if (!prims || !mats || !out || n_prims <= 0 || n_mats <= 0) return PT_FAIL("pt_scene_upload: bad arguments");
+    pt_upload_options o = {0, 0, 0};
+    if (opt) o = *opt;
+    if (o.bvh_min_prims != 0 && o.bvh_min_prims < 2) return PT_FAIL("pt_scene_upload_opt: bvh_min_prims must be 0 or >= 2");
+    if (o.bvh_leaf_prims < 0 || o.bvh_leaf_prims > 15) return PT_FAIL("pt_scene_upload_opt: bvh_leaf_prims must be 0..15");
     for (int k = 0; k < n_prims; k++) {
         if (prims[k].type < PT_PLANE || prims[k].type > PT_SPHERE) return PT_FAIL("pt_scene_upload: unknown shape type");
         if (prims[k].material < 0 || prims[k].material >= n_mats) return PT_FAIL("pt_scene_upload: material index out of range");
@@ -516,8 +548,9 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
         for (int j = 0; j < 4; j++) dp[k].bounds[j] = prims[k].bounds[j];
         dp[k].type = prims[k].type; dp[k].material = prims[k].material; dp[k].pad[0] = dp[k].pad[1] = 0;
         std::memset(&baked[k], 0, sizeof(Baked));
-        baked[k].len = bake_fast(prims[k], fwd, inv, baked[k].rec, &fs[k], &baked[k].kind);
-        world_box(prims[k], fwd, baked[k].lo, baked[k].hi);
+        baked[k].len = bake_fast(prims[k], fwd, inv, o.general_kinds == 0, baked[k].rec, &fs[k], &baked[k].kind);
+        if (prims[k].type == PT_PLANE) plane_box(prims[k], fwd, baked[k].lo, baked[k].hi);
+        else world_box(prims[k], fwd, baked[k].lo, baked[k].hi);
         all[k] = k;
         (prims[k].type == PT_PLANE ? top : finite).push_back(k);
     }
@@ -527,17 +560,16 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
     const int n_chunks = pack_runs(baked, all, fdata, runs, chunk_runs);
     std::vector<float> sorted_all, sorted_top;
     FSorted hdr_all, hdr_top;
-    pack_sorted(baked, all, sorted_all, hdr_all);
+    std::vector<float> slot_boxes;
+    pack_sorted(baked, all, sorted_all, hdr_all, &slot_boxes);
     pack_sorted(baked, top, sorted_top, hdr_top);
     std::vector<BNode> bnodes;
     std::vector<BPrim> bprims;
     std::vector<BFat> bfat;
     int fat_depth = 0;
-    int bvh_min = BVH_MIN_PRIMS;
-    if (const char* e = std::getenv("PT_BVH_MIN")) { const int v = std::atoi(e); if (v >= 2) bvh_min = v; }
+    const int bvh_min = o.bvh_min_prims ? o.bvh_min_prims : BVH_MIN_PRIMS;
     if ((int)finite.size() >= bvh_min) {
-        int leaf_prims = BVH_LEAF_PRIMS;
-        if (const char* e = std::getenv("PT_BVH_LEAF")) { const int v = std::atoi(e); if (v >= 1 && v <= 15) leaf_prims = v; }
+        const int leaf_prims = o.bvh_leaf_prims ? o.bvh_leaf_prims : BVH_LEAF_PRIMS;
         build_bvh(baked, finite, 0, (int)finite.size(), bnodes, bprims, leaf_prims);
         if (leaf_prims == 1 && finite.size() >= 2 && (int)finite.size() <= BFAT_MAX_PRIMS) {
             fat_depth = build_fat(bnodes, bfat);
@@ -553,6 +585,8 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
     for (int i = 0; i < n_mats; i++) {
         std::memset(&dm[i], 0, sizeof(DMat));
         std::memcpy(&dm[i], &mats[i], sizeof(pt_material));
+        const float* em = mats[i].emissive;
+        dm[i].emits = (fmaxf(em[0], fmaxf(em[1], em[2])) > 0.0f || fminf(em[0], fminf(em[1], em[2])) < 0.0f) ? 1 : 0;
     }
     pt_scene* sc = new (std::nothrow) pt_scene();
     if (!sc) return PT_FAIL("pt_scene_upload: out of host memory");
@@ -572,6 +606,8 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
     UP(d_fshade, fs, FShade)
     UP(d_sorted, sorted_all, float)
     sc->sorted = hdr_all; sc->sorted.data = sc->d_sorted;
+    UP(d_slot_box, slot_boxes, float)
+    sc->n_slots = n_prims;
     sc->n_runs = (int)runs.size();
     if (!bnodes.empty()) {
         UP(d_bnodes, bnodes, BNode)
@@ -602,10 +638,27 @@ int pt_scene_free(pt_scene* sc) {
     if (sc->d_bprims) (void)hipFree(sc->d_bprims);
     if (sc->d_bfat) (void)hipFree(sc->d_bfat);
     if (sc->d_sorted) (void)hipFree(sc->d_sorted);
+    if (sc->d_slot_box) (void)hipFree(sc->d_slot_box);
     if (sc->d_sorted_top) (void)hipFree(sc->d_sorted_top);
     if (sc->d_fdata_top) (void)hipFree(sc->d_fdata_top);
     if (sc->d_runs_top) (void)hipFree(sc->d_runs_top);
     delete sc;
+    return 0;
+}
+
+int pt_scene_tune(pt_scene* sc, int knob, int value) {
+    if (!sc || knob < 0 || knob >= PT_TUNE_COUNT) return PT_FAIL("pt_scene_tune: bad scene or knob");
+    bool ok = value == 0;
+    switch (knob) {
+        case PT_TUNE_TILE_LOG2: ok = ok || (value >= 2 && value <= 6); break;
+        case PT_TUNE_WALK_BUDGET: ok = ok || value >= 1; break;
+        case PT_TUNE_SHADE_GATE: ok = ok || (value >= 1 && value <= 64); break;
+        case PT_TUNE_BVH_WALK: ok = ok || value == 1; break;
+        case PT_TUNE_GLASS_QUEUE: ok = ok || value == -1 || (value >= 8 && value <= 64); break;
+        case PT_TUNE_GLASS_GATE: ok = ok || (value >= 1 && value <= 64); break;
+    }
+    if (!ok) return PT_FAIL("pt_scene_tune: value out of range for this knob");
+    sc->tune[knob] = value;
     return 0;
 }
 
@@ -660,8 +713,8 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     // primitives, 1080p, 4 spp: 263 ms with 32 pixels per wave, 216 ms with 64) — as long as that leaves two waves
     // for every wave slot of the chip.
     while (a.tile_log2 < 6 && ((uint32_t)cfg->n_samples << a.tile_log2) < 2048u && (a.n_lin >> (a.tile_log2 + 1)) >= 16384u) a.tile_log2++;
+    if (sc->tune[PT_TUNE_TILE_LOG2] != 0) a.tile_log2 = sc->tune[PT_TUNE_TILE_LOG2];
     if (cfg->tile_log2 != 0) a.tile_log2 = cfg->tile_log2;
-    if (const char* e = std::getenv("PT_TILE_LOG2")) { const int v = std::atoi(e); if (v >= 2 && v <= 6) a.tile_log2 = v; }
     a.fb_layout = cfg->fb_layout;
     a.n_prims = sc->n_prims; a.n_mats = sc->n_mats;
     a.prims = sc->d_prims; a.mats = sc->d_mats;
@@ -673,14 +726,32 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
         // PT_MATH_FAST_SCALAR and PT_MATH_FAST_LDS keep testing every primitive.
         a.bnodes = sc->d_bnodes; a.bprims = sc->d_bprims; a.n_bnodes = sc->n_bnodes;
         a.bfat = sc->d_bfat; a.walk_stack = sc->fat_depth;
-        if (const char* e = std::getenv("PT_BVH_WALK")) { if (std::strcmp(e, "skip") == 0) { a.bfat = nullptr; a.walk_budget = 32; } }
+        if (sc->tune[PT_TUNE_BVH_WALK] == 1) a.bfat = nullptr;
         a.fdata = sc->d_fdata_top; a.runs = sc->d_runs_top; a.n_runs = sc->n_runs_top;
         a.sorted = sc->sorted_top;
         // measured optimum on the 10 000-primitive scene is flat around these (a visit of the fat form decides
         // about two boxes, so its budget is half the skip-link form's)
-        a.walk_budget = sc->d_bfat ? 16 : 32; a.shade_gate = 8;
-        if (const char* e = std::getenv("PT_WALK_BUDGET")) { const int v = std::atoi(e); if (v >= 1) a.walk_budget = v; }
-        if (const char* e = std::getenv("PT_SHADE_GATE")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) a.shade_gate = v; }
+        a.walk_budget = a.bfat ? 16 : 32; a.shade_gate = 8;
+        if (sc->tune[PT_TUNE_WALK_BUDGET] != 0) a.walk_budget = sc->tune[PT_TUNE_WALK_BUDGET];
+        if (sc->tune[PT_TUNE_SHADE_GATE] != 0) a.shade_gate = sc->tune[PT_TUNE_SHADE_GATE];
+    } else if (cfg->math_mode == PT_MATH_FAST && cfg->bsdf_model == PT_BSDF_REFERENCE && sc->tune[PT_TUNE_GLASS_QUEUE] >= 0) {
+        // (the loop with camera batches and the glass queue shades with bsdf.h's tracePath only; the class-based model
+        // keeps the plain loop)
+        // The queue of set-aside glass hits: as many entries as fit beside the per-wave arrays and the tables while
+        // six workgroups still share a compute unit's 160 KiB of LDS.  Measured on the 1080p frame of the default scene
+        // (tools/q_sweep.py): 40 entries at six workgroups 3.12 ms, 24 entries at seven 3.19, 48 entries at five 3.37;
+        // free lanes take entries back from three quarters full (half full: +1.5 %, a quarter: +5 %).
+        const uint32_t P = 1u << a.tile_log2;
+        const bool tables = sc->n_prims <= 64 && sc->n_mats <= 32;
+        const size_t fixed = 4u * ((size_t)P * 28u + 2816u) + (tables ? (size_t)sc->n_prims * sizeof(FShade) + (size_t)sc->n_mats * sizeof(DMat) : 0u);
+        const size_t budget = 163840u / 6u;
+        int cap = fixed < budget ? (int)((budget - fixed) / 256u) & ~3 : 0;
+        cap = std::max(16, std::min(40, cap));
+        if (sc->tune[PT_TUNE_GLASS_QUEUE] != 0) cap = sc->tune[PT_TUNE_GLASS_QUEUE];
+        int gate = (3 * cap) / 4;
+        if (sc->tune[PT_TUNE_GLASS_GATE] != 0) gate = std::min(sc->tune[PT_TUNE_GLASS_GATE], cap);
+        a.q_cap = cap; a.q_gate = gate; a.q_inline = cap - gate + 2;   // (q_gate - 1) + (q_inline - 1) = q_cap
+        a.slot_box = sc->n_slots <= 64 ? sc->d_slot_box : nullptr; a.n_slots = sc->n_slots;
     }
     a.fb = d_fb;
     if (cfg->math_mode == PT_MATH_PARITY) return ptk_render_parity(a, (hipStream_t)stream);

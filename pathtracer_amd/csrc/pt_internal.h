@@ -31,7 +31,8 @@ struct DMat {
     float refractionRoughness;
     float refractionColor[3];
     int32_t bsdfType;
-    float pad[2];
+    int32_t emits;    // (fast kernels) some emissive component is > 0 or < 0, i.e. emissive.norm() > 0 (bsdf.h:90): the hit adds light
+    float pad;
 };
 
 // Intersection data of the fast kernels: one float array, cut into RUNS of
@@ -145,6 +146,9 @@ struct pt_scene {
     float* d_fdata_top;
     FRun* d_runs_top;
     int n_runs_top;
+    int tune[PT_TUNE_COUNT];               // pt_scene_tune: 0 = the library's choice
+    float* d_slot_box;                     // world-space box (lo.xyz, hi.xyz) of every record of `sorted`, in its order
+    int n_slots;
 };
 
 // Camera constants computed on the host in the reference's operation order
@@ -179,6 +183,13 @@ struct RenderArgs {
     int32_t n_bnodes;
     int32_t walk_budget;                   // hierarchy nodes a lane visits per loop iteration
     int32_t shade_gate;                    // lanes whose search is over before they are shaded together
+    // PT_MATH_FAST without a hierarchy: hits that need the full shading (glass, paths inside a shape) are set aside
+    // in a per-wave queue in LDS and shaded together.  q_cap = 0: the plain loop.
+    int32_t q_cap;                         // queue entries per wave (64 bytes each)
+    int32_t q_gate;                        // entries from which free lanes take them back
+    int32_t q_inline;                      // such hits in one iteration from which they stay in registers instead; (q_gate-1)+(q_inline-1) <= q_cap
+    const float* slot_box;                 // boxes of the records of `sorted` (6 floats each), or null: camera rays test every record
+    int32_t n_slots;
     float* fb;
 };
 

@@ -31,16 +31,16 @@
 // roulette, 6 accumulate, 7 (hierarchy kernels) the loop over the primitives outside the hierarchy.  Not compiled into
 // libpt_hip.so.
 #ifdef PT_PHASE_PROF
-__device__ unsigned long long g_phase_cycles[16];   // [0..7] cycles, [8..15] cycles x active lanes at the stamp
+__device__ unsigned long long g_phase_cycles[24];   // [0..7] cycles, [8..15] cycles x active lanes at the stamp, [16..23] stamps
 struct PhaseClock {
-    unsigned long long last, acc[8], lanes[8];
-    __device__ void start() { for (int i = 0; i < 8; i++) { acc[i] = 0; lanes[i] = 0; } last = __builtin_amdgcn_s_memtime(); }
+    unsigned long long last, acc[8], lanes[8], cnt[8];
+    __device__ void start() { for (int i = 0; i < 8; i++) { acc[i] = 0; lanes[i] = 0; cnt[i] = 0; } last = __builtin_amdgcn_s_memtime(); }
     __device__ void mark(int i) {
         const unsigned long long now = __builtin_amdgcn_s_memtime();
-        acc[i] += now - last; lanes[i] += (now - last) * (unsigned long long)__popcll(__ballot(1)); last = now;
+        acc[i] += now - last; lanes[i] += (now - last) * (unsigned long long)__popcll(__ballot(1)); last = now; cnt[i]++;
     }
     __device__ void flush(unsigned lane) {
-        if (lane == 0) for (int i = 0; i < 8; i++) { atomicAdd(&g_phase_cycles[i], acc[i]); atomicAdd(&g_phase_cycles[8 + i], lanes[i]); }
+        if (lane == 0) for (int i = 0; i < 8; i++) { atomicAdd(&g_phase_cycles[i], acc[i]); atomicAdd(&g_phase_cycles[8 + i], lanes[i]); atomicAdd(&g_phase_cycles[16 + i], cnt[i]); }
     }
 };
 #define PHASE(clk, i) (clk).mark(i)
@@ -487,12 +487,13 @@ struct Surf {
 
 // The winner's record: position, facing normal and the inside flag of
 // shapes.h:93-97, from the per-primitive shading record.
-PTD Surf surface(const Best& b, V3 o, V3 d, const FShade* shade) {
+// `pos` is the hit position o + d*t.
+PTD Surf surface_at(const Best& b, V3 pos, V3 d, const FShade* shade) {
     Surf s;
     const FShade& S = shade[b.id >> 3];
     const int code = b.id & 7;
     s.material = S.material;
-    s.pos = madd(d, b.t, o);
+    s.pos = pos;
     const int type = S.type;
     V3 n;
     bool inside_known = false, inside = false;
@@ -516,6 +517,7 @@ PTD Surf surface(const Best& b, V3 o, V3 d, const FShade* shade) {
     s.nrm = along ? neg(n) : n;
     return s;
 }
+PTD Surf surface(const Best& b, V3 o, V3 d, const FShade* shade) { return surface_at(b, madd(d, b.t, o), d, shade); }
 
 PTD V3 sphere_point(float u1, float u2) {            // bsdf.h:29-36; v_sin/v_cos take revolutions
     const float z = __builtin_fmaf(u1, 2.0f, -1.0f);
@@ -545,31 +547,27 @@ struct Path {
     int seg;
 };
 
-// The tracePath loop body after the nearest hit is known (bsdf.h:84-165); true = continue.
-// Written with one exit and unconditional updates of the path: a lane whose path ends here (miss, roulette, depth) is
-// refilled before its state is read again, so its o, d, coef may hold anything, and the compiler need not keep the old
-// and the new state side by side (every early return used to cost a round of register copies per iteration).
-PTD bool path_shade(Path& p, const Best& b0, const FShade* shade, const DMat* mats, int n_bounces, PhaseClock& clk) {
-    const bool hit = b0.id >= 0;
-#ifdef PT_DEBUG_KEYS
-    { const uint32_t dk[] = {PT_DEBUG_KEYS};
-      for (uint32_t q : dk) if (p.key == q) printf("DBG key %08x seg %d o %08x %08x %08x d %08x %08x %08x t %08x (%g) id %d\n", p.key, p.seg,
-          __float_as_uint(p.o.x), __float_as_uint(p.o.y), __float_as_uint(p.o.z), __float_as_uint(p.d.x), __float_as_uint(p.d.y), __float_as_uint(p.d.z), __float_as_uint(b0.t), b0.t, b0.id); }
-#endif
-    Best b = b0;
-    b.id = hit ? b0.id : 0;                            // a miss reads primitive 0's records and is dropped at the end
-    const Surf s = surface(b, p.o, p.d, shade);
-    const DMat& M = mats[s.material];
-    const V3 em = v3(M.emissive[0], M.emissive[1], M.emissive[2]);
-    PHASE(clk, 2);
-    if (hit && ((max3(em.x, em.y, em.z) > 0.0f) || (min3(em.x, em.y, em.z) < 0.0f))) p.contrib = v3(__builtin_fmaf(em.x, p.coef.x, p.contrib.x), __builtin_fmaf(em.y, p.coef.y, p.contrib.y), __builtin_fmaf(em.z, p.coef.z, p.contrib.z));
+// The tracePath loop body after the nearest hit is known (bsdf.h:84-165), in two parts: the emissive term, and
+// everything from the Beer attenuation to the roulette.  Written with one exit and unconditional updates of the path: a
+// lane whose path ends here (miss, roulette, depth) is refilled before its state is read again, so its o, d, coef may
+// hold anything, and the compiler need not keep the old and the new state side by side (every early return used to cost
+// a round of register copies per iteration).
+PTD void shade_emissive(Path& p, bool hit, const DMat& M) {      // bsdf.h:90-92; M.emits: emissive.norm() > 0, decided at upload
+    if (hit && M.emits != 0) {
+        const V3 em = v3(M.emissive[0], M.emissive[1], M.emissive[2]);
+        p.contrib = v3(__builtin_fmaf(em.x, p.coef.x, p.contrib.x), __builtin_fmaf(em.y, p.coef.y, p.contrib.y), __builtin_fmaf(em.z, p.coef.z, p.contrib.z));
+    }
+}
+
+// bsdf.h:95-165 for a hit at distance t with surface record s; true = continue.
+PTD bool shade_scatter(Path& p, const Surf& s, const DMat& M, float t, bool hit, int n_bounces, PhaseClock& clk) {
     const float f0 = M.f0, transparency = M.transparency;
     float p_specular = f0, p_refract = transparency;
     const bool glassy = (f0 > 0.0f) || (transparency > 0.0f);
     float ior = 1.0f;
     if (p.seg > 0 && s.inside) {                       // Beer attenuation, bsdf.h:95-98
         const V3 rc = v3(M.refractionColor[0], M.refractionColor[1], M.refractionColor[2]);
-        p.coef = p.coef * v3(fexp(-rc.x * b.t), fexp(-rc.y * b.t), fexp(-rc.z * b.t));
+        p.coef = p.coef * v3(fexp(-rc.x * t), fexp(-rc.y * t), fexp(-rc.z * t));
     }
     if (glassy) {
         ior = M.IOR;
@@ -604,10 +602,13 @@ PTD bool path_shade(Path& p, const Best& b0, const FShade* shade, const DMat* ma
         ndir = rd;
         tint = v3(1.0f, 1.0f, 1.0f);
     } else {
-        const V3 dd = unit(s.nrm + sphere_point(rng_u(p.key, slot + 1u), rng_u(p.key, slot + 2u)));
+        // the diffuse direction is drawn unconditionally in the reference (bsdf.h:139); a mirror-smooth specular
+        // bounce never reads it
+        const float sr = M.specularRoughness * M.specularRoughness;
+        V3 dd = v3(0.0f, 0.0f, 0.0f);
+        if (mode != 1 || sr != 0.0f) dd = unit(s.nrm + sphere_point(rng_u(p.key, slot + 1u), rng_u(p.key, slot + 2u)));
         if (mode == 1) {
             V3 sd = unit(madd(s.nrm, -2.0f * dot(p.d, s.nrm), p.d));
-            const float sr = M.specularRoughness * M.specularRoughness;
             if (sr != 0.0f) sd = unit(madd(dd, sr, sd * (1.0f - sr)));
             ndir = sd;
             tint = v3(M.specularColor[0], M.specularColor[1], M.specularColor[2]);
@@ -627,6 +628,41 @@ PTD bool path_shade(Path& p, const Best& b0, const FShade* shade, const DMat* ma
     p.o = s.pos;
     p.d = ndir;
     p.seg++;
+    return !dead && p.seg <= n_bounces;
+}
+
+// The whole loop body: surface record and material of the winner, then the two parts above.
+PTD bool path_shade(Path& p, const Best& b0, const FShade* shade, const DMat* mats, int n_bounces, PhaseClock& clk) {
+    const bool hit = b0.id >= 0;
+#ifdef PT_DEBUG_KEYS
+    { const uint32_t dk[] = {PT_DEBUG_KEYS};
+      for (uint32_t q : dk) if (p.key == q) printf("DBG key %08x seg %d o %08x %08x %08x d %08x %08x %08x t %08x (%g) id %d\n", p.key, p.seg,
+          __float_as_uint(p.o.x), __float_as_uint(p.o.y), __float_as_uint(p.o.z), __float_as_uint(p.d.x), __float_as_uint(p.d.y), __float_as_uint(p.d.z), __float_as_uint(b0.t), b0.t, b0.id); }
+#endif
+    Best b = b0;
+    b.id = hit ? b0.id : 0;                            // a miss reads primitive 0's records and is dropped at the end
+    const Surf s = surface(b, p.o, p.d, shade);
+    const DMat& M = mats[s.material];
+    PHASE(clk, 2);
+    shade_emissive(p, hit, M);
+    return shade_scatter(p, s, M, b.t, hit, n_bounces, clk);
+}
+
+// What is left of the loop body for a hit on a material with f0 = 0 and transparency = 0 that is not reached from
+// inside (no Beer term): mode 3 with p_ray = 1 (bsdf.h:130-133,139,152-165).  `keep` lanes (hits that need the full
+// shade_scatter) come out with d, coef and seg unchanged and o moved to the hit position.
+PTD bool shade_diffuse(Path& p, const Surf& s, const DMat& M, bool hit, bool keep, int n_bounces) {
+    const uint32_t slot = 2u + 6u * (uint32_t)p.seg;
+    const V3 dd = unit(s.nrm + sphere_point(rng_u(p.key, slot + 1u), rng_u(p.key, slot + 2u)));
+    V3 coef = p.coef * v3(M.albedo[0], M.albedo[1], M.albedo[2]);
+    const float q = max3(coef.x, coef.y, coef.z);
+    bool dead = !hit || q <= 0.0f;
+    if (!(q >= 1.0f)) dead = dead || rng_u(p.key, slot + 5u) > q;
+    coef = coef * rcp(q);
+    p.coef = v3(keep ? p.coef.x : coef.x, keep ? p.coef.y : coef.y, keep ? p.coef.z : coef.z);
+    p.d = v3(keep ? p.d.x : dd.x, keep ? p.d.y : dd.y, keep ? p.d.z : dd.z);
+    p.o = s.pos;
+    p.seg += keep ? 0 : 1;
     return !dead && p.seg <= n_bounces;
 }
 
@@ -865,6 +901,415 @@ struct FastTracer {
     static PTD void phase(FastCtx& c, int i) { PHASE(c.clk, i); (void)c; (void)i; }
 };
 
+
+// ---- PT_MATH_FAST without a hierarchy: camera rays in batches, glass hits set aside ------------------------------
+//
+// The plain loop (render_tile) treats every segment alike: each iteration tests all primitives for all 64 lanes and
+// runs the whole of shade_scatter.  Two things are different here.
+//
+// Camera rays in batches.  The first segment of 64 samples is traced by all 64 lanes at once (camera_batch): rays
+// are made, tested and shaded together, and what continues is parked in LDS as a secondary ray of 32 bytes (origin,
+// RNG key | direction, pixel and material) for a lane of the main loop to pick up; paths that end at their first hit
+// add their light to the pixel at once.  The rays of a batch leave one point towards a few adjacent pixels, so most
+// of the scene cannot be hit by any of them: once per tile, lane l tests the box of record l against the tile's view
+// pyramid (tile_candidates) and the ballot of the survivors is the list of records the batches test.  The main loop
+// is then left with secondary segments only.
+//
+// Glass hits set aside.  In the plain loop every iteration runs Beer term, Fresnel ratio, mode draw, reflected and
+// refracted directions for the few lanes whose hit needs them (7 % of the hits of the default scene), at the price
+// of a full wave each time.  Here the loop body shades the common case only (shade_diffuse).  A lane whose hit
+// needs more writes its path and hit to a small queue in LDS and is free for new work at once; when enough have
+// gathered (q_gate), free lanes take them back and shade_scatter runs for all of them together.  If many lanes need
+// it in the same iteration (q_inline or more: a wave looking at glass) they keep their state in registers instead and
+// are shaded at the same place one iteration later; camera rays that hit glass are parked with their hit and join
+// them.  The queue never holds more than (q_gate - 1) + (q_inline - 1) <= q_cap entries: after the take-back step
+// it is below q_gate (it takes whenever it holds q_gate or more, and the lanes that put entries in are free by
+// then), and fewer than q_inline are put in per iteration.
+//
+// Arithmetic per path is the plain loop's, and pixel sums do not depend on the order of the additions, so the image
+// is the plain loop's bit for bit (PT_MATH_FAST_SCALAR keeps the plain loop; tested).
+template <class T> PTD T* lds_ptr(uint32_t off) { return (T*)(T __attribute__((address_space(3)))*)(uintptr_t)off; }
+PTD uint32_t lds_off(const void* p) { return (uint32_t)(uintptr_t)(const void __attribute__((address_space(3)))*)p; }
+PTD uint32_t uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+
+struct BatchLds {            // one wave's share of the launch's dynamic LDS
+    unsigned long long* acc; // [3*P] pixel sums, 32.32 fixed point
+    uint32_t* out_px;        // [P] framebuffer slot of each tile pixel
+    float4* stash;           // [2][64] parked work: secondary ray (origin, key | direction, pixel | material << 8), or a
+                             // camera ray with a hit that needs shade_scatter (t, id, -, key | direction, pixel | 1 << 31)
+    float4* gq;              // [4][q_cap] set-aside hits: (pos, t) | (d, id) | (coef, key) | (contrib, seg << 8 | pixel)
+};
+constexpr uint32_t STASH_FLAG = 0x80000000u;
+
+// Dynamic LDS of the launch, in this order: per wave [acc 3*P u64 | gq 4*q_cap float4 | stash 128 float4 |
+// pxt 192 float | out_px P u32], then (LDS_TABLES) the shading records and the materials.
+__host__ __device__ inline size_t batched_wave_bytes(uint32_t P, uint32_t q_cap) { return (size_t)P * 24u + (size_t)q_cap * 64u + 2048u + 768u + (size_t)P * 4u; }
+// A wave's arrays from the LDS address of its block.
+PTD void carve_wave_lds(uint32_t base, uint32_t P, uint32_t q_cap, BatchLds& L, FastCtx& ctx) {
+    L.acc = lds_ptr<unsigned long long>(base);
+    L.gq = lds_ptr<float4>(base + P * 24u);
+    L.stash = L.gq + 4u * q_cap;
+    ctx.pxt = reinterpret_cast<float*>(L.stash + 128);
+    L.out_px = reinterpret_cast<uint32_t*>(ctx.pxt + 192);
+}
+
+PTD void add_light(const BatchLds& L, uint32_t px, V3 c) {
+    __hip_atomic_fetch_add(&L.acc[px * 3u], ptw::to_fixed(c.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __hip_atomic_fetch_add(&L.acc[px * 3u + 1u], ptw::to_fixed(c.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __hip_atomic_fetch_add(&L.acc[px * 3u + 2u], ptw::to_fixed(c.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+// Which records of the kind-sorted table can a camera ray of this tile hit?  Bit s = record s (records are numbered
+// through the kinds in FP_* order).  Camera rays are cam + t * (X, Y, Z0) with Z0 = p00.z - cam.z and (X, Y) inside
+// the rectangle the tile's pixels span on the sample plane (main.cu:40-63; jitter included, one pixel of margin).
+// Lane s projects box s onto that plane, clipped to the half space in front of the camera, by interval arithmetic;
+// a box whose projection misses the rectangle is dropped.  Anything undecidable (NaN from inf/inf, a box around the
+// camera) fails the "misses" compare and stays in.
+PTD unsigned long long tile_candidates(const RenderArgs& a, uint32_t lin_base, uint32_t npx, unsigned lane) {
+    if (a.slot_box == nullptr || a.n_slots > 64) return ~0ull;
+    const uint32_t W = (uint32_t)a.max_x;
+    const uint32_t k0 = lin_base / W, k1 = (lin_base + npx - 1u) / W;
+    const uint32_t i0 = k0 == k1 ? lin_base - k0 * W : 0u, i1 = k0 == k1 ? lin_base + npx - 1u - k0 * W : W - 1u;
+    const int j0 = a.row_begin + (int)k0 * a.row_step, j1 = a.row_begin + (int)k1 * a.row_step;
+    // sample-plane coordinates (main.cu:62): sx = i - 0.5 + U, sy = max_y - j - 0.5 + U, U in (0,1]
+    const float sx0 = (float)i0 - 1.5f, sx1 = (float)i1 + 1.5f;
+    const float sy0 = (float)(a.max_y - max(j0, j1)) - 1.5f, sy1 = (float)(a.max_y - min(j0, j1)) + 1.5f;
+    const float xa = a.du * sx0 + (a.p00[0] - a.cam[0]), xb = a.du * sx1 + (a.p00[0] - a.cam[0]);
+    const float ya = a.dv * sy0 + (a.p00[1] - a.cam[1]), yb = a.dv * sy1 + (a.p00[1] - a.cam[1]);
+    const float X0 = __builtin_fminf(xa, xb), X1 = __builtin_fmaxf(xa, xb), Y0 = __builtin_fminf(ya, yb), Y1 = __builtin_fmaxf(ya, yb);
+    const float Z0 = a.p00[2] - a.cam[2];
+    bool keep = false;
+    if ((int)lane < a.n_slots) {
+        const float* B = a.slot_box + 6 * lane;
+        const float lx = B[0] - a.cam[0], ly = B[1] - a.cam[1], lz = B[2] - a.cam[2];
+        const float hx = B[3] - a.cam[0], hy = B[4] - a.cam[1], hz = B[5] - a.cam[2];
+        // ray parameter t = z / Z0 over the box; only t > 0 is in front of the camera
+        const float ta = lz / Z0, tb = hz / Z0;
+        const float t_hi = __builtin_fmaxf(ta, tb);
+        const float t_lo = __builtin_fmaxf(__builtin_fminf(ta, tb), 1e-30f);
+        const float slack = 1e-4f;
+        // projection x / t over x in [lx, hx], t in [t_lo, t_hi] (t > 0): lowest from lx, highest from hx
+        const float px_lo = __builtin_fminf(lx / t_lo, lx / t_hi), px_hi = __builtin_fmaxf(hx / t_lo, hx / t_hi);
+        const float py_lo = __builtin_fminf(ly / t_lo, ly / t_hi), py_hi = __builtin_fmaxf(hy / t_lo, hy / t_hi);
+        const float mx = slack * (__builtin_fabsf(X0) + __builtin_fabsf(X1)), my = slack * (__builtin_fabsf(Y0) + __builtin_fabsf(Y1));
+        const bool misses = (t_hi <= 0.0f) || (px_hi < X0 - mx) || (px_lo > X1 + mx) || (py_hi < Y0 - my) || (py_lo > Y1 + my);
+        keep = !misses;
+    }
+    return __ballot(keep);
+}
+
+// scan_sorted over the records whose bit is set in `mask` (bit s = record s, numbered through the kinds in FP_*
+// order, which is the order of this function).  Same tests, same (distance, index) rule: the result is scan_sorted's
+// whenever no record that the ray hits is masked out.
+PTD void scan_sorted_masked(V3 o, V3 d, float dd, float idd, const FSorted& S, unsigned long long mask, Best& b) {
+    const KFloatP base = as_constant(S.data);
+    const V3 inv = v3(rcp(d.x), rcp(d.y), rcp(d.z));
+    int first = 0;
+#define PT_KIND_LOOP(KIND, STRIDE, ID_AT, CALL)                                                              \
+    {                                                                                                        \
+        const int cnt = S.count[KIND];                                                                       \
+        unsigned long long m = cnt > 0 ? (mask >> first) & (cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull)) : 0ull; \
+        first += cnt;                                                                                        \
+        for (; m != 0ull; m &= m - 1ull) {                                                                   \
+            const KFloatP R = base + S.off[KIND] + __builtin_ctzll(m) * (STRIDE);                            \
+            const int id = __float_as_int(R[ID_AT]);                                                         \
+            CALL;                                                                                            \
+        }                                                                                                    \
+    }
+    PT_KIND_LOOP(FP_PLANE, 16, 12, test_plane(R, o, d, id, b))
+    PT_KIND_LOOP(FP_CUBE, 16, 12, test_cube(R, o, d, id, b))
+    PT_KIND_LOOP(FP_CYLINDER, 16, 12, test_cylinder(R, o, d, id, b))
+    PT_KIND_LOOP(FP_SPHERE, 16, 12, test_sphere(R, o, d, id, b))
+    PT_KIND_LOOP(FP_SPHERE_WS, 8, 4, test_sphere_ws(R, o, d, dd, idd, id, b))
+    PT_KIND_LOOP(FP_PLANE_GEN, 20, 16, test_plane_gen(R, o, d, id, b))
+    PT_KIND_LOOP(FP_PLANE_X, 8, 5, test_plane_axis<0>(R, o, d, inv, id, b))
+    PT_KIND_LOOP(FP_PLANE_Y, 8, 5, test_plane_axis<1>(R, o, d, inv, id, b))
+    PT_KIND_LOOP(FP_PLANE_Z, 8, 5, test_plane_axis<2>(R, o, d, inv, id, b))
+    PT_KIND_LOOP(FP_CUBE_AA, 8, 6, test_cube_box(R, o, inv, id, b))
+#undef PT_KIND_LOOP
+}
+
+// The first segment of pool items made .. made + 63, one per lane: camera ray (main.cu:62-64), nearest hit among the
+// tile's candidate records, surface, emissive term and — for a hit that shade_diffuse covers — new direction and
+// roulette.  What goes on is parked in L.stash, packed from entry 0; returns the number of entries.
+template <bool SORTED>
+PTD uint32_t camera_batch(const RenderArgs& a, FastCtx& ctx, const BatchLds& L, const SceneRefs& sc, unsigned long long cand,
+                          uint32_t made, uint32_t total, uint32_t lin_base, uint32_t npx, unsigned lane) {
+    using T = FastTracer<0, SORTED>;
+    const uint32_t lg = (uint32_t)a.tile_log2, P = 1u << lg;
+    const uint32_t w = made + lane;
+    const uint32_t px = w & (P - 1u);
+    const bool valid = w < total && px < npx;
+    float4 ray;
+    T::make_ray(a, ctx, px, lin_base + px, w >> lg, ray);
+    const V3 o = v3(a.cam[0], a.cam[1], a.cam[2]), d = v3(ray.x, ray.y, ray.z);
+    const uint32_t key = __float_as_uint(ray.w);
+    Best b0 = best_none();
+    {
+        const float dd = dot(d, d), idd = rcp(dd);
+        if (SORTED) {
+            if (a.slot_box != nullptr && a.n_slots <= 64) scan_sorted_masked(o, d, dd, idd, sc.sorted, cand, b0);
+            else scan_sorted(o, d, dd, idd, sc.sorted, b0);
+        } else {
+            scan_runs(o, d, dd, idd, as_constant(sc.fdata), as_constant(sc.runs), 0, sc.n_runs, b0);
+        }
+    }
+    const bool hit = valid && b0.id >= 0;
+    Best b = b0;
+    b.id = hit ? b0.id : 0;
+    const Surf s = surface(b, o, d, ctx.shade);
+    const DMat& M = ctx.mats[s.material];
+    // the path so far: coefficient 1, no light; shade_emissive and shade_diffuse as the main loop runs them
+    ptf::Path p;
+    p.o = o; p.d = d; p.coef = v3(1.0f, 1.0f, 1.0f); p.contrib = v3(0.0f, 0.0f, 0.0f); p.key = key; p.seg = 0;
+    shade_emissive(p, hit, M);
+    const bool lit = (p.contrib.x != 0.0f) || (p.contrib.y != 0.0f) || (p.contrib.z != 0.0f);
+    const bool special = hit && ((M.f0 != 0.0f) || (M.transparency != 0.0f));
+    const V3 light = p.contrib;
+    const bool go_on = shade_diffuse(p, s, M, hit, false, a.n_bounces);
+    // a secondary ray carries no light of its own: a hit that is lit and goes on keeps its camera ray and is shaded
+    // again from its hit, with the hits that need shade_scatter anyway
+    const bool as_hit = special || (hit && go_on && lit);
+    const bool as_ray = hit && go_on && !as_hit;
+    if (hit && !as_hit && !go_on && lit) add_light(L, px, light);
+    const unsigned long long park = __ballot(as_hit || as_ray);
+    const uint32_t e = ptw::prefix_count(park);
+    if (as_ray) {
+        L.stash[e] = make_float4(p.o.x, p.o.y, p.o.z, __uint_as_float(key));
+        L.stash[64u + e] = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(px | ((uint32_t)s.material << 8)));
+    }
+    if (as_hit) {
+        L.stash[e] = make_float4(b.t, __int_as_float(b.id), 0.0f, __uint_as_float(key));
+        L.stash[64u + e] = make_float4(d.x, d.y, d.z, __uint_as_float(px | STASH_FLAG));
+    }
+    return (uint32_t)__popcll(park);
+}
+
+template <bool LDS_TABLES, bool SORTED>
+PTD void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds& L, FastCtx& ctx) {
+    using T = FastTracer<0, SORTED>;
+    enum { FREE = 0, ACTIVE = 1, GLASS = 2 };
+    const unsigned lane = ptw::lane_id();
+    const uint32_t lg = (uint32_t)a.tile_log2, P = 1u << lg;
+    const uint32_t lin_base = tile << lg;
+    const uint32_t npx = min(P, a.n_lin - lin_base);
+    const uint32_t total = (uint32_t)a.n_samples << lg;
+#ifdef PT_CONST_Q
+    constexpr uint32_t QC = 24, QG = 18, QI = 8;
+#else
+    const uint32_t QC = (uint32_t)a.q_cap, QG = (uint32_t)a.q_gate, QI = (uint32_t)a.q_inline;
+#endif
+
+    for (uint32_t k = lane; k < 3u * P; k += 64u) L.acc[k] = 0ull;
+    if (lane < npx) {
+        const ptw::PixelRef ref = ptw::pixel_of(a, lin_base + lane);
+        L.out_px[lane] = ref.out;
+        T::prologue(a, ctx, lane, ref);
+    }
+#ifdef PT_NO_CULL
+    const unsigned long long cand = ~0ull;
+#else
+    const unsigned long long cand = tile_candidates(a, lin_base, npx, lane);
+#endif
+#ifdef PT_DEBUG_CAND
+    if (lane == 0 && (tile % 4001u) == 0u) printf("tile %u lin_base %u cand %016llx\n", tile, lin_base, cand);
+#endif
+
+    ptf::Path path;
+    T::idle(path);
+    uint32_t my_px = 0;
+    int st = FREE;
+    float ht = 0.0f;                 // a GLASS lane's hit: distance and code; its position is path.o
+    int hid = 0;
+    bool camera_hit = false;         // ... and whether it is a camera ray's, whose emissive term is still to be added
+    uint32_t made = 0;               // wave-uniform: pool items the batches have traced
+    uint32_t parked = 0;             // wave-uniform: entries in the stash
+    uint32_t qn = 0;                 // wave-uniform: entries in the queue
+    SceneRefs sc;
+    sc.fdata = a.fdata; sc.runs = a.runs; sc.n_runs = a.n_runs;
+    sc.nodes = nullptr; sc.bprims = nullptr; sc.n_nodes = 0; sc.fat = nullptr; sc.sorted = a.sorted;
+    for (;;) {
+        // wave-uniform by construction; said once per iteration so that the compiler keeps them in scalar registers
+        made = uniform(made); parked = uniform(parked); qn = uniform(qn);
+        // 1. free lanes take set-aside hits back
+        unsigned long long want = __ballot(st == FREE);
+        if (want != 0ull && qn != 0u && (qn >= QG || __ballot(st == GLASS) != 0ull || (made >= total && parked == 0u))) {
+            const uint32_t rank = ptw::prefix_count(want);
+            const uint32_t take = min((uint32_t)__popcll(want), qn);
+            if (st == FREE && rank < take) {
+                const uint32_t e = qn - 1u - rank;
+                const float4 r0 = L.gq[e], r1 = L.gq[QC + e], r2 = L.gq[2u * QC + e], r3 = L.gq[3u * QC + e];
+                path.o = v3(r0.x, r0.y, r0.z); ht = r0.w;
+                path.d = v3(r1.x, r1.y, r1.z); hid = __float_as_int(r1.w);
+                path.coef = v3(r2.x, r2.y, r2.z); path.key = __float_as_uint(r2.w);
+                path.contrib = v3(r3.x, r3.y, r3.z);
+                const uint32_t sp = __float_as_uint(r3.w);
+                path.seg = (int)(sp >> 8); my_px = sp & 255u;
+                camera_hit = false;
+                st = GLASS;
+            }
+            qn -= take;
+            want = __ballot(st == FREE);
+        }
+        // 2. parked work for the lanes that are still free: what is parked, then a camera batch if that was not
+        //    enough, then what the batch parked (lanes it cannot serve wait one iteration)
+        uint32_t need = (uint32_t)__popcll(want);
+        if (need != 0u) {
+            const uint32_t rank = ptw::prefix_count(want);
+            uint32_t served = 0;
+            for (int pass = 0; pass < 2 && need != 0u; pass++) {
+                if (parked == 0u) {
+                    if (made >= total) break;
+                    parked = camera_batch<SORTED>(a, ctx, L, sc, cand, made, total, lin_base, npx, lane);
+#ifdef PT_BATCH_ONLY
+                    parked = 0;
+#endif
+                    made = min(made + 64u, total);
+                    PHASE(ctx.clk, 7);
+                }
+                const uint32_t take = min(need, parked);
+                if (st == FREE && rank >= served && rank < served + take) {
+                    const uint32_t e = parked - 1u - (rank - served);
+                    const float4 A = L.stash[e], B = L.stash[64u + e];
+                    const uint32_t meta = __float_as_uint(B.w);
+                    my_px = meta & 255u;
+                    path.d = v3(B.x, B.y, B.z);
+                    path.key = __float_as_uint(A.w);
+                    path.contrib = v3(0.0f, 0.0f, 0.0f);
+                    if (meta & STASH_FLAG) {
+                        ht = A.x; hid = __float_as_int(A.y);
+                        path.o = madd(path.d, ht, v3(a.cam[0], a.cam[1], a.cam[2]));
+                        path.coef = v3(1.0f, 1.0f, 1.0f);
+                        path.seg = 0;
+                        camera_hit = true;
+                        st = GLASS;
+                    } else {
+                        // throughput after the first hit, as shade_diffuse left it: albedo / max(albedo)
+                        const DMat& M = ctx.mats[(meta & ~STASH_FLAG) >> 8];
+                        const V3 alb = v3(M.albedo[0], M.albedo[1], M.albedo[2]);
+                        path.o = v3(A.x, A.y, A.z);
+                        path.coef = alb * rcp(max3(alb.x, alb.y, alb.z));
+                        path.seg = 1;
+                        st = ACTIVE;
+                    }
+                }
+                parked -= take; served += take; need -= take;
+            }
+        }
+        PHASE(ctx.clk, 0);
+        // 3. the full shading for the lanes that hold a hit which needs it
+        if (__ballot(st == GLASS) != 0ull) {
+            if (st == GLASS) {
+                Best b; b.t = ht; b.id = hid;
+                const Surf s = surface_at(b, path.o, path.d, ctx.shade);
+                const DMat& M = ctx.mats[s.material];
+                shade_emissive(path, camera_hit, M);
+                const bool go_on = shade_scatter(path, s, M, ht, true, a.n_bounces, ctx.clk);
+                st = ACTIVE;
+                if (!go_on) {
+                    add_light(L, my_px, path.contrib);
+                    st = FREE;
+                }
+            }
+        }
+        PHASE(ctx.clk, 3);
+        if (__ballot(st != FREE) == 0ull) {
+            if (made >= total && parked == 0u && qn == 0u) break;
+            continue;
+        }
+        // 4. one segment for every lane (a free lane steps whatever state it holds; the result is dropped)
+        Best b0 = best_none();
+        {
+            const float dd = dot(path.d, path.d), idd = rcp(dd);
+            if (SORTED) scan_sorted(path.o, path.d, dd, idd, sc.sorted, b0);
+            else scan_runs(path.o, path.d, dd, idd, as_constant(sc.fdata), as_constant(sc.runs), 0, sc.n_runs, b0);
+        }
+        PHASE(ctx.clk, 1);
+        const bool hit = b0.id >= 0;
+        Best b = b0;
+        b.id = hit ? b0.id : 0;                        // a miss reads primitive 0's records and is dropped below
+        const Surf s = surface(b, path.o, path.d, ctx.shade);
+        const DMat& M = ctx.mats[s.material];
+        PHASE(ctx.clk, 2);
+        shade_emissive(path, hit, M);
+        const bool special = hit && st == ACTIVE && ((M.f0 != 0.0f) || (M.transparency != 0.0f) || (path.seg > 0 && s.inside));
+        // 5. hits that need the full shading: into the queue (the lane is free at once), or kept in registers
+        const unsigned long long special_m = __ballot(special);
+        bool keep = false;
+        if (special_m != 0ull) {
+            const uint32_t g = (uint32_t)__popcll(special_m);
+            if (g >= QI || qn + g > QC) {
+                keep = special;
+            } else {
+                if (special) {
+                    const uint32_t e = qn + ptw::prefix_count(special_m);
+                    L.gq[e] = make_float4(s.pos.x, s.pos.y, s.pos.z, b.t);
+                    L.gq[QC + e] = make_float4(path.d.x, path.d.y, path.d.z, __int_as_float(b.id));
+                    L.gq[2u * QC + e] = make_float4(path.coef.x, path.coef.y, path.coef.z, __uint_as_float(path.key));
+                    L.gq[3u * QC + e] = make_float4(path.contrib.x, path.contrib.y, path.contrib.z, __uint_as_float(((uint32_t)path.seg << 8) | my_px));
+                    st = FREE;
+                }
+                qn += g;
+            }
+        }
+        if (keep) { st = GLASS; ht = b.t; hid = b.id; camera_hit = false; }
+        PHASE(ctx.clk, 4);
+        // 6. the common case for everyone else
+        const bool go_on = shade_diffuse(path, s, M, hit, keep, a.n_bounces);
+        PHASE(ctx.clk, 5);
+        if (st == ACTIVE && !go_on) {
+            add_light(L, my_px, path.contrib);
+            st = FREE;
+        }
+        PHASE(ctx.clk, 6);
+    }
+    // p_color = totalLight / n_samples (main.cu:67); consecutive floats of consecutive pixels leave together
+    const float ns = (float)a.n_samples;
+    if (a.fb_layout == PT_FB_AOS) {
+        for (uint32_t f = lane; f < npx * 3u; f += 64u) {
+            const uint32_t px = (f * 43691u) >> 17;          // f / 3 for f < 2^16
+            a.fb[(size_t)L.out_px[px] * 3u + (f - px * 3u)] = ptw::from_fixed(L.acc[f]) / ns;
+        }
+    } else {
+        const size_t plane = a.fb_compact ? (size_t)a.n_lin : (size_t)a.max_x * (size_t)a.max_y;
+        if (lane < npx)
+            for (int c = 0; c < 3; c++) a.fb[c * plane + L.out_px[lane]] = ptw::from_fixed(L.acc[lane * 3 + c]) / ns;
+    }
+}
+
+template <bool LDS_TABLES, bool SORTED>
+__global__ __launch_bounds__(ptw::BLOCK) void render_fast_batched_kernel(RenderArgs a, uint32_t n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    const uint32_t P = 1u << a.tile_log2;
+    const size_t per_wave = batched_wave_bytes(P, (uint32_t)a.q_cap);
+    FastCtx ctx;
+    if (LDS_TABLES) {
+        // The whole workgroup copies the shading and material tables into LDS once.
+        FShade* lshade = reinterpret_cast<FShade*>(dyn_lds + per_wave * ptw::WAVES_PER_BLOCK);
+        DMat* lmats = reinterpret_cast<DMat*>(lshade + a.n_prims);
+        const uint32_t* gs = reinterpret_cast<const uint32_t*>(a.fshade);
+        uint32_t* ls = reinterpret_cast<uint32_t*>(lshade);
+        for (uint32_t w = threadIdx.x; w < (uint32_t)a.n_prims * (sizeof(FShade) / 4); w += ptw::BLOCK) ls[w] = gs[w];
+        const uint32_t* gm = reinterpret_cast<const uint32_t*>(a.mats);
+        uint32_t* lm = reinterpret_cast<uint32_t*>(lmats);
+        for (uint32_t w = threadIdx.x; w < (uint32_t)a.n_mats * (sizeof(DMat) / 4); w += ptw::BLOCK) lm[w] = gm[w];
+        __syncthreads();
+        ctx.shade = lshade; ctx.mats = lmats;
+    } else {
+        ctx.shade = a.fshade; ctx.mats = a.mats;
+    }
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * ptw::WAVES_PER_BLOCK + wave;
+    if (tile >= n_tiles) return;
+    const uint32_t wave_lds = lds_off(dyn_lds + per_wave * wave);
+    BatchLds L;
+    carve_wave_lds(wave_lds, P, (uint32_t)a.q_cap, L, ctx);
+    ctx.wstack = nullptr;
+    ctx.clk.start();
+    render_tile_batched<LDS_TABLES, SORTED>(a, tile, L, ctx);
+    ctx.clk.flush(threadIdx.x & 63);
+}
+
 template <bool LDS_TABLES, int BVH, bool SORTED>
 __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, uint32_t n_tiles) {
     __shared__ ptw::WaveLds lds[ptw::WAVES_PER_BLOCK];
@@ -949,8 +1394,8 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(SceneRefs sc,
 #ifdef PT_PHASE_PROF
 extern "C" int pt_dev_phase_cycles(unsigned long long* out, int reset) {
     PT_CHECK(hipDeviceSynchronize());
-    PT_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(unsigned long long)));
-    if (reset) { unsigned long long z[16] = {0}; PT_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z))); }
+    PT_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 24 * sizeof(unsigned long long)));
+    if (reset) { unsigned long long z[24] = {0}; PT_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z))); }
     return 0;
 }
 #endif
@@ -981,8 +1426,15 @@ int ptk_render_fast(const RenderArgs& a, int variant, hipStream_t s) {
         }
     } else {
         const bool tables = a.n_prims <= LDS_MAX_PRIMS && a.n_mats <= LDS_MAX_MATS;
-        const bool sorted = variant == PT_MATH_FAST && std::getenv("PT_LOOP_RUNS") == nullptr;   // PT_MATH_FAST_SCALAR: the runs, in scene order
-        if (sorted) {
+        const bool sorted = variant == PT_MATH_FAST;   // PT_MATH_FAST_SCALAR: the runs, in scene order, plain loop
+        if (sorted && a.q_cap > 0) {
+            // The loop with camera batches and the glass queue.  All of its LDS is dynamic: per-wave arrays sized by the tile, the
+            // queue by q_cap, the tables by the scene.
+            const size_t table_bytes = tables ? (size_t)a.n_prims * sizeof(FShade) + (size_t)a.n_mats * sizeof(DMat) : 0;
+            const size_t lds = batched_wave_bytes(1u << a.tile_log2, (uint32_t)a.q_cap) * ptw::WAVES_PER_BLOCK + table_bytes;
+            if (tables) hipLaunchKernelGGL((render_fast_batched_kernel<true, true>), dim3(blocks), dim3(ptw::BLOCK), lds, s, a, n_tiles);
+            else hipLaunchKernelGGL((render_fast_batched_kernel<false, true>), dim3(blocks), dim3(ptw::BLOCK), lds, s, a, n_tiles);
+        } else if (sorted) {
             if (tables) hipLaunchKernelGGL((render_fast_kernel<true, 0, true>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
             else hipLaunchKernelGGL((render_fast_kernel<false, 0, true>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
         } else {

@@ -226,12 +226,8 @@ plane glow     bounds -0.5 -0.5 0.5 0.5  translate 0 -2 -3
     ref = osc.trace_paths(o, d, px.astype(np.uint32), sm.astype(np.uint32), seed=0, n_bounces=0)
     assert (ref.sum(axis=1) > 0).mean() > 0.03 and (ref.sum(axis=1) == 0).mean() > 0.1
     assert ref[0].sum() == 0
-    for bvh_min in ("2", "1000000"):              # through the hierarchy and through the loop
-        os.environ["PT_BVH_MIN"] = bvh_min
-        try:
-            sc = pt.Scene(prims, n, mats, nm)
-        finally:
-            del os.environ["PT_BVH_MIN"]
+    for bvh_min in (2, 1000000):                  # through the hierarchy and through the loop
+        sc = pt.Scene(prims, n, mats, nm, bvh_min_prims=bvh_min)
         for mode in (pt.PT_MATH_PARITY, pt.PT_MATH_FAST):
             rgb = sc.trace_paths(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda(), torch.from_numpy(px).cuda(),
                                  torch.from_numpy(sm).cuda(), seed=0, n_bounces=0, math_mode=mode).cpu().numpy()
@@ -290,12 +286,8 @@ def test_fast_hit_decisions_on_random_scenes(oracle, n_shapes, seed, aligned):
     hit_frac = (ref[:, 0] > 0).mean()
     assert hit_frac > 0.3
     assert len(np.unique(ref[:, 0])) >= min(n_shapes, 10)          # many different primitives are first hits
-    for bvh_min in ("2", "1000000"):
-        os.environ["PT_BVH_MIN"] = bvh_min
-        try:
-            sc = pt.Scene(prims, n, mats, nm)
-        finally:
-            del os.environ["PT_BVH_MIN"]
+    for bvh_min in (2, 1000000):
+        sc = pt.Scene(prims, n, mats, nm, bvh_min_prims=bvh_min)
         for mode in (pt.PT_MATH_PARITY, pt.PT_MATH_FAST):
             rgb = sc.trace_paths(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda(), torch.from_numpy(px).cuda(),
                                  torch.from_numpy(sm).cuda(), seed=0, n_bounces=0, math_mode=mode).cpu().numpy()

@@ -79,16 +79,9 @@ def test_glass_grid_depth_31_full_frame(torch, pt):
 def test_glass_grid_depth_31_hierarchy_equals_loop_at_full_size():
     """36 large glass spheres, 32 segments, 1080p: through the hierarchy and through the loop over all primitives,
     bit for bit (long paths inside glass reach rays with direction components of exactly 0)."""
-    import os
     import torch
     import pathtracer_amd as pt
-    scenes = []
-    for bvh_min in ("2", "1000000"):
-        os.environ["PT_BVH_MIN"] = bvh_min
-        try:
-            scenes.append(pt.Scene(*pt.glass_grid_scene(6)))
-        finally:
-            del os.environ["PT_BVH_MIN"]
+    scenes = [pt.Scene(*pt.glass_grid_scene(6), bvh_min_prims=bvh_min) for bvh_min in (2, 1000000)]
     assert scenes[0].bvh_nodes > 0 and scenes[1].bvh_nodes == 0
     cfg = pt.make_config(1920, 1080, 16, n_bounces=31)
     a, b = scenes[0].render(cfg), scenes[1].render(cfg)

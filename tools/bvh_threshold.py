@@ -17,10 +17,8 @@ def timed(sc, cfg, reps=3):
 cases = [("synthetic %d+%d" % (a, b), lambda a=a, b=b: pt.synthetic_scene(a, b, 12345), 5) for a, b in ((16, 16), (24, 24), (32, 32), (52, 52), (100, 100))]
 cases += [("glass grid %dx%d depth 31" % (g, g), lambda g=g: pt.glass_grid_scene(g), 31) for g in (6, 8, 10, 12)]
 for name, build, depth in cases:
-    os.environ["PT_BVH_MIN"] = "2"
-    with_h = pt.Scene(*build())
-    os.environ["PT_BVH_MIN"] = "1000000"
-    without = pt.Scene(*build())
+    with_h = pt.Scene(*build(), bvh_min_prims=2)
+    without = pt.Scene(*build(), bvh_min_prims=1000000)
     cfg = pt.make_config(1920, 1080, 16, n_bounces=depth)
     a, ta = timed(with_h, cfg)
     b, tb = timed(without, cfg)

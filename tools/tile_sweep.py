@@ -22,6 +22,6 @@ for n in (1, 2, 3, 4, 6, 8, 16):
     cfg = pt.make_config(W, H, SPP, row_begin=0, row_step=n, fb_compact=1)
     line = []
     for lg in (6, 5, 4, 3):
-        os.environ["PT_TILE_LOG2"] = str(lg)
+        sc.tune(pt.binding.PT_TUNE_TILE_LOG2, lg)
         line.append("P=%d %.3f" % (1 << lg, time_cfg(cfg)))
     print("N=%2d (%7d px): %s" % (n, len(range(0, H, n)) * W, "  ".join(line)), flush=True)

@@ -15,10 +15,10 @@ def timed():
         ts.append(e0.elapsed_time(e1))
     return min(ts)
 for walk in ("fat", "skip"):
-    os.environ["PT_BVH_WALK"] = walk
+    sc.tune(pt.binding.PT_TUNE_BVH_WALK, 1 if walk == "skip" else 0)
     for budget in (4, 8, 16, 32, 64, 1000000):
         row = []
         for gate in (1, 8, 16, 32, 64):
-            os.environ["PT_WALK_BUDGET"] = str(budget); os.environ["PT_SHADE_GATE"] = str(gate)
+            sc.tune(pt.binding.PT_TUNE_WALK_BUDGET, budget).tune(pt.binding.PT_TUNE_SHADE_GATE, gate)
             row.append("%.2f" % timed())
         print(walk, "budget", budget, "gate 1/8/16/32/64:", " ".join(row), flush=True)
