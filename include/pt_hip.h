@@ -107,12 +107,14 @@ typedef struct pt_scene pt_scene; /* opaque; owns the device copy of the primiti
 int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, int n_mats, int device, pt_scene** out);
 /* The same with explicit build options (NULL = the defaults, which is what pt_scene_upload uses).  No counterpart
  * in the reference.  They change how PT_MATH_FAST searches the scene, never which hit it finds. */
+enum { PT_GENERAL_PLANES = 1, PT_GENERAL_CUBES = 2, PT_GENERAL_SPHERES = 4, PT_GENERAL_ALL = 7 };
 typedef struct pt_upload_options {
     int32_t bvh_min_prims;  /* finite primitives (spheres, cubes, cylinders) from which PT_MATH_FAST builds a
                              * bounding-volume hierarchy; 0 = the default (96), values >= 2 */
     int32_t bvh_leaf_prims; /* primitives per leaf, 1..15; 0 = the default (1) */
-    int32_t general_kinds;  /* non-zero: planes and cubes along the world axes keep the general record kinds
-                             * (the tests a rotated scene gets) */
+    int32_t general_kinds;  /* PT_GENERAL_* bits: these shapes keep the general record kinds, tested in local space
+                             * as shapes.h does, instead of the shorter world-space tests that axis-aligned planes,
+                             * unrotated cubes and uniformly scaled spheres otherwise get */
 } pt_upload_options;
 int pt_scene_upload_opt(const pt_prim* prims, int n_prims, const pt_material* mats, int n_mats, int device,
                         const pt_upload_options* opt, pt_scene** out);

@@ -47,6 +47,7 @@ class pt_upload_options(C.Structure):
     _fields_ = [("bvh_min_prims", C.c_int32), ("bvh_leaf_prims", C.c_int32), ("general_kinds", C.c_int32)]
 
 
+PT_GENERAL_PLANES, PT_GENERAL_CUBES, PT_GENERAL_SPHERES, PT_GENERAL_ALL = 1, 2, 4, 7
 PT_TUNE_TILE_LOG2, PT_TUNE_WALK_BUDGET, PT_TUNE_SHADE_GATE, PT_TUNE_BVH_WALK, PT_TUNE_GLASS_QUEUE, PT_TUNE_GLASS_GATE = range(6)
 
 
@@ -239,7 +240,7 @@ class Scene:
         self.n, self.n_mats, self.device = n, n_mats, device
         h = C.c_void_p(0)
         if bvh_min_prims or bvh_leaf_prims or general_kinds:
-            opt = pt_upload_options(bvh_min_prims, bvh_leaf_prims, 1 if general_kinds else 0)
+            opt = pt_upload_options(bvh_min_prims, bvh_leaf_prims, PT_GENERAL_ALL if general_kinds is True else int(general_kinds))
             _check(lib.pt_scene_upload_opt(prims, n, mats, n_mats, device, C.byref(opt), C.byref(h)))
         else:
             _check(lib.pt_scene_upload(prims, n, mats, n_mats, device, C.byref(h)))

@@ -133,7 +133,7 @@ float len3(float x, float y, float z) { return sqrtf(x * x + y * y + z * z); }
 
 // Kind, intersection record and shading record of the fast kernels for one
 // shape.  Returns the record length in floats.
-int bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, bool axis_kinds, float* rec, FShade* fs, int32_t* ftype) {
+int bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, int general, float* rec, FShade* fs, int32_t* ftype) {
     std::memset(fs, 0, sizeof(*fs));
     fs->type = p.type; fs->material = p.material;
     // Columns of L and the unit normals along them.  The reference forms a normal as normalize(T*axis - wOrigin)
@@ -175,7 +175,7 @@ int bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, bool axis_kinds,
                 // rotation by (float)(pi/2) or (float)pi leaves where a zero belongs, 4e-8 to 9e-8 of the row, counts
                 // as zero; the limit is 2e-7, the size of a float rounding.
                 int axis[3] = {-1, -1, -1};
-                bool aligned = axis_kinds;
+                bool aligned = (general & PT_GENERAL_PLANES) == 0;
                 for (int r = 0; r < 3 && aligned; r++) {
                     const float* row = rec + 4 * r;
                     int a = 0;
@@ -221,7 +221,7 @@ int bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, bool axis_kinds,
             const float tol = 1e-6f * l0 * l0;
             const bool uniform = l0 > 0.0f && fabsf(l0 - l1) <= 1e-6f * l0 && fabsf(l0 - l2) <= 1e-6f * l0 &&
                                  fabsf(dotc(0, 1)) <= tol && fabsf(dotc(0, 2)) <= tol && fabsf(dotc(1, 2)) <= tol;
-            if (uniform) {
+            if (uniform && (general & PT_GENERAL_SPHERES) == 0) {
                 *ftype = FP_SPHERE_WS;
                 rec[0] = fwd.m[0][3]; rec[1] = fwd.m[1][3]; rec[2] = fwd.m[2][3];
                 const float rad = 0.5f * l0;
@@ -236,7 +236,7 @@ int bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, bool axis_kinds,
             for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) fs->a[j * 3 + i] = ncol[j][i];
             // Diagonal L (off-diagonal entries below 2e-7 of their column's diagonal entry): the cube is a box along
             // the world axes and is tested there, local axis i being world axis i.
-            bool diagonal = axis_kinds;
+            bool diagonal = (general & PT_GENERAL_CUBES) == 0;
             for (int j = 0; j < 3 && diagonal; j++) {
                 if (fwd.m[j][j] == 0.0f) diagonal = false;
                 for (int i = 0; i < 3; i++) if (i != j && fabsf(fwd.m[i][j]) > 2e-7f * fabsf(fwd.m[j][j])) diagonal = false;
@@ -548,7 +548,7 @@ int pt_scene_upload_opt(const pt_prim* prims, int n_prims, const pt_material* ma
         for (int j = 0; j < 4; j++) dp[k].bounds[j] = prims[k].bounds[j];
         dp[k].type = prims[k].type; dp[k].material = prims[k].material; dp[k].pad[0] = dp[k].pad[1] = 0;
         std::memset(&baked[k], 0, sizeof(Baked));
-        baked[k].len = bake_fast(prims[k], fwd, inv, o.general_kinds == 0, baked[k].rec, &fs[k], &baked[k].kind);
+        baked[k].len = bake_fast(prims[k], fwd, inv, o.general_kinds, baked[k].rec, &fs[k], &baked[k].kind);
         if (prims[k].type == PT_PLANE) plane_box(prims[k], fwd, baked[k].lo, baked[k].hi);
         else world_box(prims[k], fwd, baked[k].lo, baked[k].hi);
         all[k] = k;
@@ -708,7 +708,10 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     // 1080p frame and its interleaved row sets: 32 is best from 1.5 Mpixel, 16 from 0.2 Mpixel, 8 below, 64 only
     // for frames several times 1080p.  The image does not depend on this choice (pixel sums are exact
     // fixed-point sums).
-    a.tile_log2 = a.n_lin >= 6000000u ? 6 : (a.n_lin >= 1500000u ? 5 : (a.n_lin >= 200000u ? 4 : 3));
+    // The loop with camera batches keeps 32 up to the largest frames (3840x2160 @ 1024: 181 ms against 202 with 64).
+    const bool batched = cfg->math_mode == PT_MATH_FAST && cfg->bsdf_model == PT_BSDF_REFERENCE && sc->n_bnodes == 0 &&
+                         sc->tune[PT_TUNE_GLASS_QUEUE] >= 0;
+    a.tile_log2 = (a.n_lin >= 6000000u && !batched) ? 6 : (a.n_lin >= 1500000u ? 5 : (a.n_lin >= 200000u ? 4 : 3));
     // ... and a pool of at least ~2048 samples per wave, or the drain phase dominates at low sample counts (10 000
     // primitives, 1080p, 4 spp: 263 ms with 32 pixels per wave, 216 ms with 64) — as long as that leaves two waves
     // for every wave slot of the chip.
@@ -734,7 +737,7 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
         a.walk_budget = a.bfat ? 16 : 32; a.shade_gate = 8;
         if (sc->tune[PT_TUNE_WALK_BUDGET] != 0) a.walk_budget = sc->tune[PT_TUNE_WALK_BUDGET];
         if (sc->tune[PT_TUNE_SHADE_GATE] != 0) a.shade_gate = sc->tune[PT_TUNE_SHADE_GATE];
-    } else if (cfg->math_mode == PT_MATH_FAST && cfg->bsdf_model == PT_BSDF_REFERENCE && sc->tune[PT_TUNE_GLASS_QUEUE] >= 0) {
+    } else if (batched) {
         // (the loop with camera batches and the glass queue shades with bsdf.h's tracePath only; the class-based model
         // keeps the plain loop)
         // The queue of set-aside glass hits: as many entries as fit beside the per-wave arrays and the tables while

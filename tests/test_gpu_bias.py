@@ -1,0 +1,72 @@
+"""Bias of the fast kernels, separated from branch-flip noise.
+
+At one seed the fast and the parity-order kernel trace the same random streams; where a rounding difference flips a
+branch, the two paths part and the pixel differs by an unrelated Monte-Carlo sample.  That noise has zero mean and is
+independent from seed to seed, so the difference of the SEED-AVERAGED images must shrink like 1/sqrt(S); a systematic
+error of the fast arithmetic would not shrink.  The per-pixel RMSE bounds elsewhere cannot tell the two apart."""
+import numpy as np
+import pytest
+
+import tolerances as tol
+
+pytestmark = pytest.mark.gpu
+
+W, H, SPP, SEEDS = 128, 72, 16, 32
+
+
+def _seed_averaged_difference(pt, scene, depth):
+    diffs = []
+    par_mean = 0.0
+    for seed in range(SEEDS):
+        f = scene.render(pt.make_config(W, H, SPP, n_bounces=depth, seed=seed, math_mode=pt.PT_MATH_FAST)).double()
+        p = scene.render(pt.make_config(W, H, SPP, n_bounces=depth, seed=seed, math_mode=pt.PT_MATH_PARITY)).double()
+        diffs.append((f - p).cpu().numpy())
+        par_mean = par_mean + p.mean(dim=(0, 1)).cpu().numpy() / SEEDS
+    return np.stack(diffs), par_mean
+
+
+def _rms_by_group_size(d, par_mean):
+    rms = {}
+    for s in (1, 2, 4, 8, 16, 32):
+        # mean over disjoint groups of s seeds, then the RMS over pixels, channels and groups
+        groups = d[: (SEEDS // s) * s].reshape(SEEDS // s, s, H, W, 3).mean(axis=1)
+        rms[s] = float(np.sqrt((groups ** 2).mean()))
+    return rms, {s: v / par_mean.mean() for s, v in rms.items()}
+
+
+@pytest.mark.parametrize("name,depth,general", [("default", 5, 0), ("glass grid, spheres tested in local space", 31, 4)])
+def test_fast_minus_parity_shrinks_with_the_number_of_seeds(pt, name, depth, general):
+    from pathtracer_amd import binding as b
+    assert general in (0, b.PT_GENERAL_SPHERES)
+    scene = pt.Scene(*(pt.default_scene() if name == "default" else pt.glass_grid_scene(5)), general_kinds=general)
+    d, par_mean = _seed_averaged_difference(pt, scene, depth)
+    rms, rel = _rms_by_group_size(d, par_mean)
+    print("%s: RMS of the seed-averaged difference / mean radiance: %s" % (name, {s: "%.4f" % v for s, v in rel.items()}))
+    assert rms[1] > 0.0                                                  # the two kernels do differ somewhere
+    assert rel[1] <= 3.0 * tol.fast_image_rmse(SPP)                      # one seed: branch-flip noise (small frame, depth 31: x3)
+    # noise law: each doubling of the seeds takes sqrt(2) off; a bias floor would stop the fall
+    assert rms[32] <= 1.35 * rms[1] / np.sqrt(32.0), rel
+    bias = np.abs(d.mean(axis=(0, 1, 2))) / par_mean                     # per channel, all seeds and pixels
+    print("%s: per-channel mean of fast - parity over %d seeds, relative: %s" % (name, SEEDS, bias))
+    assert (bias <= tol.FAST["bias_mean_rel"]).all(), bias
+
+
+def test_known_bias_of_world_space_spheres_on_the_glass_grid(pt):
+    """The one systematic difference found so far.  Uniformly scaled spheres are tested in world space by default.
+    The reference tests them in a local frame in which a small sphere far from the origin has coordinates of
+    magnitude |centre| / scale, so its hit positions and its next test of the same sphere carry larger rounding
+    errors: a ray reflected at a grazing angle re-hits its own sphere beyond the 1e-5 filter of shapes.h:62-73 more
+    often there (and is lost) than in the world-space test.  The oracle and the parity-order kernels reproduce that;
+    the fast default does it less often, so pixels on the rims of the spheres nearest the light come out
+    brighter (up to +40 % of the pixel; 1.5 % of the pixels by more than a tenth of the mean radiance; +0.3 % in the mean).  Bounded here; PT_GENERAL_SPHERES (tested above) removes it at 7 % of the frame time."""
+    scene = pt.Scene(*pt.glass_grid_scene(5))
+    d, par_mean = _seed_averaged_difference(pt, scene, 31)
+    rms, rel = _rms_by_group_size(d, par_mean)
+    mean_bias = d.mean(axis=(0, 1, 2)) / par_mean
+    per_pixel = np.abs(d.mean(axis=0)).max(axis=2) / par_mean.mean()
+    print("glass grid, world-space spheres: RMS %s, mean bias %s, pixels above 10 %%: %.4f" % (
+        {s: "%.4f" % v for s, v in rel.items()}, mean_bias, (per_pixel > 0.1).mean()))
+    assert (np.abs(mean_bias) <= tol.FAST["bias_mean_rel_glass"]).all()
+    assert (mean_bias > 0.0).all()                                       # brighter, not darker
+    assert (per_pixel > 0.1).mean() <= 0.025                             # confined to the rims of a few spheres (measured 1.5 % of the pixels)
+    assert rel[32] <= 0.06

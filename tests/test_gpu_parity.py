@@ -19,6 +19,8 @@ import os
 import numpy as np
 import pytest
 
+import tolerances as tol
+
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -174,9 +176,9 @@ def test_render_256_vs_golden(torch, pt, oracle, mode):
     st = image_stats(img, gold)
     print("render 256x256@16 %s: %s" % (mode, st))
     assert np.isfinite(img).all()
-    assert st["rmse_rel"] <= (0.01 if mode == "parity" else 0.02)
+    assert st["rmse_rel"] <= (tol.PARITY["image_rmse"] if mode == "parity" else tol.fast_image_rmse(16))
     assert st["bad_frac"] <= (0.001 if mode == "parity" else 0.005)
-    assert st["mean_rel"] <= 0.005
+    assert st["mean_rel"] <= tol.FAST["mean_rel"]
 
 
 def test_render_is_deterministic_and_tiling_independent(torch, pt):
@@ -254,7 +256,7 @@ def test_render_1080p_properties(torch, pt):
     p = sc.render(pt.make_config(1920, 1080, 64, math_mode=pt.PT_MATH_PARITY))
     ma, mp = a.mean(dim=(0, 1)).cpu().numpy(), p.mean(dim=(0, 1)).cpu().numpy()
     print("1080p mean radiance fast %s parity %s" % (ma, mp))
-    np.testing.assert_allclose(ma, mp, rtol=5e-3)
+    np.testing.assert_allclose(ma, mp, rtol=tol.FAST["mean_rel"])
     bad = ((a - p).abs().amax(dim=2) > 0.05).float().mean().item()
     print("1080p fast vs parity: fraction of pixels off by > 0.05: %.5f" % bad)
     assert bad <= 0.005
@@ -294,9 +296,9 @@ def test_alternative_bsdf_model(torch, pt, oracle):
     rmse_f = np.sqrt(((fast - img_ref) ** 2).mean()) / mean
     bad_f = (np.abs(fast - img_ref).max(axis=2) > 0.05).mean()
     print("alternative bsdf: parity rmse %.2e bad %.5f | fast rmse %.2e bad %.5f" % (rmse_p, bad_p, rmse_f, bad_f))
-    assert rmse_p <= 0.01 and bad_p <= 0.001               # the bar of the bsdf.h path: RMSE <= 1 % of the mean
-    assert bad_f <= 0.02
-    np.testing.assert_allclose(fast.mean(axis=(0, 1)), img_ref.mean(axis=(0, 1)), rtol=0.03)
+    assert rmse_p <= tol.PARITY["image_rmse"] and bad_p <= tol.PARITY["bad_pixel_frac"]   # the bar of the bsdf.h path
+    assert bad_f <= tol.CLASSES_BSDF["fast_bad_pixel_frac"]
+    np.testing.assert_allclose(fast.mean(axis=(0, 1)), img_ref.mean(axis=(0, 1)), rtol=tol.CLASSES_BSDF["fast_mean_rel"])
     # LDS-staged loop, hierarchy and explicit rays run the same shading code
     a = sc.render(pt.make_config(w, h, spp, math_mode=pt.PT_MATH_FAST_SCALAR, bsdf_model=pt.PT_BSDF_CLASSES))
     b = sc.render(pt.make_config(w, h, spp, math_mode=pt.PT_MATH_FAST_LDS, bsdf_model=pt.PT_BSDF_CLASSES))
