@@ -213,20 +213,18 @@ int bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, int general, flo
         }
         case PT_SPHERE: {
             fs->a[0] = fwd.m[0][3]; fs->a[1] = fwd.m[1][3]; fs->a[2] = fwd.m[2][3];
-            // L = s * R (orthogonal columns of equal length): the local quadratic
-            // equals the world one with centre t and radius s/2.
-            const float l0 = len3(col[0][0], col[0][1], col[0][2]), l1 = len3(col[1][0], col[1][1], col[1][2]),
-                        l2 = len3(col[2][0], col[2][1], col[2][2]);
-            auto dotc = [&](int a, int b) { return col[a][0] * col[b][0] + col[a][1] * col[b][1] + col[a][2] * col[b][2]; };
-            const float tol = 1e-6f * l0 * l0;
-            const bool uniform = l0 > 0.0f && fabsf(l0 - l1) <= 1e-6f * l0 && fabsf(l0 - l2) <= 1e-6f * l0 &&
-                                 fabsf(dotc(0, 1)) <= tol && fabsf(dotc(0, 2)) <= tol && fabsf(dotc(1, 2)) <= tol;
-            if (uniform && (general & PT_GENERAL_SPHERES) == 0) {
+            // L = s * I exactly (what Affine3f::scale(s) on an unrotated transform gives): the local frame is a scale
+            // and an offset, read off T^-1 as the reference computes it
+            const bool scaled_identity = fwd.m[0][0] != 0.0f && fwd.m[0][0] == fwd.m[1][1] && fwd.m[0][0] == fwd.m[2][2] &&
+                                         fwd.m[0][1] == 0.0f && fwd.m[0][2] == 0.0f && fwd.m[1][0] == 0.0f && fwd.m[1][2] == 0.0f &&
+                                         fwd.m[2][0] == 0.0f && fwd.m[2][1] == 0.0f &&
+                                         inv.m[0][0] == inv.m[1][1] && inv.m[0][0] == inv.m[2][2];
+            if (scaled_identity && (general & PT_GENERAL_SPHERES) == 0) {
                 *ftype = FP_SPHERE_WS;
-                rec[0] = fwd.m[0][3]; rec[1] = fwd.m[1][3]; rec[2] = fwd.m[2][3];
-                const float rad = 0.5f * l0;
-                rec[3] = rad * rad;
-                return 4;
+                const float k = inv.m[0][0];
+                rec[0] = k; rec[1] = inv.m[0][3]; rec[2] = inv.m[1][3]; rec[3] = inv.m[2][3];
+                rec[4] = k * k; rec[5] = 1.0f / (k * k);
+                return 6;
             }
             *ftype = FP_SPHERE;
             put_inv();

@@ -44,7 +44,8 @@ struct DMat {
 //   FP_PLANE_GEN (16) : rows z, x, y of T^-1 (12) | xMin, yMin, xMax, yMax
 //   FP_PLANE_X/Y/Z (5): a bounded plane whose normal and edges run along world axes (normal along x/y/z, edges
 //                       along the other two, u < v): plane coordinate | centre, half-width along u | the same along v
-//   FP_SPHERE_WS (4)  : centre.xyz, radius^2   (L = s*R: tested in world space)
+//   FP_SPHERE_WS (6)  : a sphere under L = s*I: k = 1/s | q = -centre/s | k^2 | 1/k^2  (the reference's local frame
+//                       o_l = k*o + q without the matrix; the name is historical: it used to be a world-space test)
 //   FP_SPHERE, FP_CUBE, FP_CYLINDER (12): rows of T^-1
 //   FP_CUBE_AA (6)    : a cube under a diagonal L (no rotation): world-space box, low corner | high corner
 // The float array is cut into chunks of FDATA_CHUNK floats; no record and no run crosses a chunk boundary, so a

@@ -161,9 +161,21 @@ PTD void take_quadratic(float a, float ia, float h, float c, int id, Best& b) {
     b.id = ok ? id : b.id;
 }
 
+// Sphere under L = s * I (uniform scale, no rotation).  The reference's local frame (shapes.h:42-48,327-343) is then
+// o_l = k*o + q and d_l = k*d with k = 1/s, q = -centre/s (record: k | q | k^2 | 1/k^2), so no matrix is needed — but
+// the test is still made in that frame, product and sum rounded as the reference rounds them: for a small sphere far
+// from the origin o_l is the difference of two numbers of magnitude |centre|/s, and it is that cancellation which
+// decides whether a ray leaving the sphere at a grazing angle finds it again beyond the 1e-5 filter.  (Tested in
+// world space instead — |o - centre|^2 - r^2 — such rays are lost less often than in the reference: a measurable
+// bias on the rims of small bright spheres.)  dd = d.d and idd = 1/dd are the caller's.
 template <class RP> PTD void test_sphere_ws(RP R, V3 o, V3 d, float dd, float idd, int id, Best& b) {
-    const V3 oc = o - v3(R[0], R[1], R[2]);
-    take_quadratic(dd, idd, dot(oc, d), dot(oc, oc) - R[3], id, b);
+    const float k = R[0];
+    V3 ol;
+    {
+#pragma clang fp contract(off)
+        ol = v3(o.x * k + R[1], o.y * k + R[2], o.z * k + R[3]);
+    }
+    take_quadratic(R[4] * dd, R[5] * idd, k * dot(d, ol), dot(ol, ol) - 0.25f, id, b);
 }
 
 template <class RP> PTD void test_sphere(RP R, V3 o, V3 d, int id, Best& b) {
@@ -283,7 +295,7 @@ PTD void scan_runs(V3 o, V3 d, float dd, float idd, RP base, KIntP runs, int r0,
                 break;
             }
             case FP_SPHERE_WS:
-                for (int i = 0; i < run.count; i++, R += 4, id += 8) test_sphere_ws(R, o, d, dd, idd, id, b);
+                for (int i = 0; i < run.count; i++, R += 6, id += 8) test_sphere_ws(R, o, d, dd, idd, id, b);
                 break;
             case FP_CUBE:
                 for (int i = 0; i < run.count; i++, R += 12, id += 8) test_cube(R, o, d, id, b);
@@ -352,7 +364,7 @@ PTD void scan_sorted(V3 o, V3 d, float dd, float idd, const FSorted& S, Best& b)
     }
     {
         KFloatP R = base + S.off[FP_SPHERE_WS];
-        for (int i = S.count[FP_SPHERE_WS]; i > 0; i--, R += 8) test_sphere_ws(R, o, d, dd, idd, __float_as_int(R[4]), b);
+        for (int i = S.count[FP_SPHERE_WS]; i > 0; i--, R += 8) test_sphere_ws(R, o, d, dd, idd, __float_as_int(R[6]), b);
     }
     {
         KFloatP R = base + S.off[FP_SPHERE];
@@ -1020,7 +1032,7 @@ PTD void scan_sorted_masked(V3 o, V3 d, float dd, float idd, const FSorted& S, u
     PT_KIND_LOOP(FP_CUBE, 16, 12, test_cube(R, o, d, id, b))
     PT_KIND_LOOP(FP_CYLINDER, 16, 12, test_cylinder(R, o, d, id, b))
     PT_KIND_LOOP(FP_SPHERE, 16, 12, test_sphere(R, o, d, id, b))
-    PT_KIND_LOOP(FP_SPHERE_WS, 8, 4, test_sphere_ws(R, o, d, dd, idd, id, b))
+    PT_KIND_LOOP(FP_SPHERE_WS, 8, 6, test_sphere_ws(R, o, d, dd, idd, id, b))
     PT_KIND_LOOP(FP_PLANE_GEN, 20, 16, test_plane_gen(R, o, d, id, b))
     PT_KIND_LOOP(FP_PLANE_X, 8, 5, test_plane_axis<0>(R, o, d, inv, id, b))
     PT_KIND_LOOP(FP_PLANE_Y, 8, 5, test_plane_axis<1>(R, o, d, inv, id, b))
