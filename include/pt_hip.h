@@ -195,6 +195,25 @@ int pt_trace_paths_alt(const pt_scene* scene, const float* d_o, const float* d_d
                        const uint32_t* d_sample, int n_rays, uint32_t seed, int n_bounces, int math_mode,
                        float* d_rgb, void* stream);
 
+/* The helper functions of bsdf.h and vec_math.h on arrays, one element per thread, in either family of kernels:
+ * what tracePath calls per segment, reachable on its own (the reference has no such entry point: they are
+ * __device__ functions).  d_in: [n][n_in] floats, d_out: [n][n_out] floats, both on `device`.
+ *   fn                        n_in                               n_out   reference
+ *   PT_FN_SAMPLE_HEMISPHERE   2: u1 u2                           3       sampleHemisphere, bsdf.h:29-36
+ *   PT_FN_FRESNEL_SCHLICK     3: n1 n2 cosTheta                  1       FresnelSchlick, bsdf.h:48-51
+ *   PT_FN_FRESNEL_RATIO       10: N(3) I(3) f0 f90 n1 n2         1       getFresnelRatio, bsdf.h:53-69
+ *   PT_FN_REFLECT             6: v(3) n(3)                       3       reflect, vec_math.h:19-21
+ *   PT_FN_REFRACT             7: I(3) N(3) eta                   3       refract, vec_math.h:23-30 (0 vector on total reflection)
+ *   PT_FN_LERP                7: v0(3) v1(3) t                   3       lerp<vec3>, vec_math.h:10-12
+ *   PT_FN_NORMALIZED          3: v                               3       Eigen's .normalized() (0 vector stays 0)
+ * math_mode: PT_MATH_PARITY (the reference's operation order) or PT_MATH_FAST (what the fast kernels evaluate:
+ * v_sin/v_cos in revolutions, v_rcp, v_rsq, fused multiply-adds). */
+enum { PT_FN_SAMPLE_HEMISPHERE = 0, PT_FN_FRESNEL_SCHLICK = 1, PT_FN_FRESNEL_RATIO = 2, PT_FN_REFLECT = 3, PT_FN_REFRACT = 4,
+       PT_FN_LERP = 5, PT_FN_NORMALIZED = 6, PT_FN_COUNT = 7 };
+int pt_bsdf_batch(int device, int fn, int math_mode, const float* d_in, int n, float* d_out, void* stream);
+/* Floats per element going in and coming out of `fn` (0 on success). */
+int pt_bsdf_arity(int fn, int* n_in, int* n_out);
+
 /* Raw draws of the counter RNG: bits and (0,1] uniforms of slots [0,n_slots) of
  * stream (seed, pixel, sample), computed on the device. */
 int pt_rng_draws(int device, uint32_t seed, uint32_t pixel, uint32_t sample, int n_slots,

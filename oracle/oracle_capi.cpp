@@ -272,6 +272,27 @@ void oracle_trace_paths_alt(void* scene, const float* o, const float* d, const u
 }
 
 // Raw RNG access: bits and uniforms of draw slots [0, n_slots) of one stream.
+// The helper functions of bsdf.h / vec_math.h on arrays; fn and the array shapes as pt_bsdf_batch of the product's ABI:
+// 0 sampleHemisphere (2 -> 3), 1 FresnelSchlick (3 -> 1), 2 getFresnelRatio (10 -> 1), 3 reflect (6 -> 3),
+// 4 refract (7 -> 3), 5 lerp<vec3> (7 -> 3), 6 vec3::normalized (3 -> 3).
+int oracle_bsdf_batch(int fn, const float* in, int n, float* out) {
+    for (int i = 0; i < n; i++) {
+        vec3 r(0, 0, 0);
+        switch (fn) {
+            case 0: r = sampleHemisphere(in[2 * i], in[2 * i + 1]); break;
+            case 1: out[i] = FresnelSchlick(in[3 * i], in[3 * i + 1], in[3 * i + 2]); continue;
+            case 2: { const float* a = in + 10 * i; out[i] = getFresnelRatio(vec3(a[0], a[1], a[2]), vec3(a[3], a[4], a[5]), a[6], a[7], a[8], a[9]); continue; }
+            case 3: { const float* a = in + 6 * i; r = reflect(vec3(a[0], a[1], a[2]), vec3(a[3], a[4], a[5])); break; }
+            case 4: { const float* a = in + 7 * i; r = refract(vec3(a[0], a[1], a[2]), vec3(a[3], a[4], a[5]), a[6]); break; }
+            case 5: { const float* a = in + 7 * i; r = lerp(vec3(a[0], a[1], a[2]), vec3(a[3], a[4], a[5]), a[6]); break; }
+            case 6: r = vec3(in[3 * i], in[3 * i + 1], in[3 * i + 2]).normalized(); break;
+            default: return -1;
+        }
+        out[3 * i] = r.x(); out[3 * i + 1] = r.y(); out[3 * i + 2] = r.z();
+    }
+    return 0;
+}
+
 void oracle_rng(unsigned seed, unsigned pixel, unsigned sample, int n_slots, unsigned* bits, float* uniforms) {
     pt_rng s = rng_init(seed, pixel, sample);
     for (int k = 0; k < n_slots; k++) {

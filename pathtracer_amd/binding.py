@@ -81,6 +81,8 @@ def _load():
     L.pt_trace_paths.argtypes = [vp, vp, vp, vp, vp, i32, u32, i32, i32, vp, vp]
     L.pt_trace_paths_alt.argtypes = [vp, vp, vp, vp, vp, i32, u32, i32, i32, vp, vp]
     L.pt_rng_draws.argtypes = [i32, u32, u32, u32, i32, vp, vp, vp]
+    L.pt_bsdf_batch.argtypes = [i32, i32, i32, vp, i32, vp, vp]
+    L.pt_bsdf_arity.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
     L.pt_ppm_p3.restype = C.c_long
     L.pt_ppm_p3.argtypes = [vp, i32, i32, C.c_char_p, C.c_long]
     L.pt_ppm_p6.restype = C.c_long
@@ -106,7 +108,7 @@ lib = _load()
 EXPORTS = [
     "pt_scene_upload", "pt_scene_upload_opt", "pt_scene_tune", "pt_scene_free", "pt_scene_device", "pt_scene_bvh_nodes", "pt_default_scene", "pt_glass_grid_scene",
     "pt_synthetic_scene", "pt_focal_length", "pt_render", "pt_raypath_batch", "pt_nearest_batch",
-    "pt_trace_paths", "pt_trace_paths_alt", "pt_rng_draws", "pt_ppm_p3", "pt_last_error", "pt_version",
+    "pt_trace_paths", "pt_trace_paths_alt", "pt_rng_draws", "pt_bsdf_batch", "pt_bsdf_arity", "pt_ppm_p3", "pt_last_error", "pt_version",
     "pt_scene_parse", "pt_ppm_p6", "pt_pfm",
     "pt_tile_rows", "pt_comm_unique_id", "pt_comm_init_rank", "pt_comm_init_all", "pt_comm_free", "pt_comm_rank",
     "pt_comm_world", "pt_gather_framebuffer", "pt_assemble_rows", "pt_gather_framebuffer_noalloc",
@@ -327,6 +329,21 @@ def rng_draws(seed, pixel, sample, n_slots, device=0):
     with torch.cuda.device(device):
         _check(lib.pt_rng_draws(device, seed, pixel, sample, n_slots, _ptr(bits), _ptr(u), _stream()))
     return bits, u
+
+
+PT_FN_SAMPLE_HEMISPHERE, PT_FN_FRESNEL_SCHLICK, PT_FN_FRESNEL_RATIO, PT_FN_REFLECT, PT_FN_REFRACT, PT_FN_LERP, PT_FN_NORMALIZED = range(7)
+
+
+def bsdf_batch(fn, x, math_mode=PT_MATH_PARITY, device=0):
+    """pt_bsdf_batch: the helper functions of bsdf.h / vec_math.h on the rows of the device tensor x."""
+    torch = _torch()
+    n_in, n_out = C.c_int(0), C.c_int(0)
+    _check(lib.pt_bsdf_arity(fn, C.byref(n_in), C.byref(n_out)))
+    x = x.contiguous().view(-1, n_in.value)
+    out = torch.zeros((x.shape[0], n_out.value), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(device):
+        _check(lib.pt_bsdf_batch(device, fn, math_mode, _ptr(x), x.shape[0], _ptr(out), _stream()))
+    return out
 
 
 PT_COMM_ID_BYTES = 128

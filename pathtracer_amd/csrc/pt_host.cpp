@@ -806,6 +806,23 @@ int pt_trace_paths_alt(const pt_scene* sc, const float* d_o, const float* d_d, c
                        n_bounces, math_mode, PT_BSDF_CLASSES, d_rgb, stream);
 }
 
+int pt_bsdf_arity(int fn, int* n_in, int* n_out) {
+    static const int in[PT_FN_COUNT] = {2, 3, 10, 6, 7, 7, 3}, out[PT_FN_COUNT] = {3, 1, 1, 3, 3, 3, 3};
+    if (fn < 0 || fn >= PT_FN_COUNT) return PT_FAIL("pt_bsdf_arity: unknown function");
+    if (n_in) *n_in = in[fn];
+    if (n_out) *n_out = out[fn];
+    return 0;
+}
+
+int pt_bsdf_batch(int device, int fn, int math_mode, const float* d_in, int n, float* d_out, void* stream) {
+    if (fn < 0 || fn >= PT_FN_COUNT) return PT_FAIL("pt_bsdf_batch: unknown function");
+    if (n < 0 || (n > 0 && (!d_in || !d_out))) return PT_FAIL("pt_bsdf_batch: bad arguments");
+    if (math_mode != PT_MATH_PARITY && math_mode != PT_MATH_FAST) return PT_FAIL("pt_bsdf_batch: math_mode must be PT_MATH_PARITY or PT_MATH_FAST");
+    PT_CHECK(hipSetDevice(device));
+    if (math_mode == PT_MATH_PARITY) return ptk_bsdf_batch_parity(fn, d_in, n, d_out, (hipStream_t)stream);
+    return ptk_bsdf_batch_fast(fn, d_in, n, d_out, (hipStream_t)stream);
+}
+
 int pt_rng_draws(int device, uint32_t seed, uint32_t pixel, uint32_t sample, int n_slots,
                  uint32_t* d_bits, float* d_uniforms, void* stream) {
     if (n_slots < 0) return PT_FAIL("pt_rng_draws: bad arguments");

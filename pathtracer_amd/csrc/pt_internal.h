@@ -206,6 +206,8 @@ int ptk_trace_paths_parity(const pt_scene* sc, const float* o, const float* d, c
                            const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, int bsdf_model, float* rgb, hipStream_t s);
 int ptk_trace_paths_fast(const pt_scene* sc, const float* o, const float* d, const uint32_t* pixel,
                          const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, int bsdf_model, float* rgb, hipStream_t s);
+int ptk_bsdf_batch_parity(int fn, const float* in, int n, float* out, hipStream_t s);
+int ptk_bsdf_batch_fast(int fn, const float* in, int n, float* out, hipStream_t s);
 int ptk_rng_draws(uint32_t seed_hash, uint32_t pixel, uint32_t sample, int n_slots, uint32_t* bits, float* u, hipStream_t s);
 
 // Records "HIP error = <n> at <file>:<line> '<expr>'" for pt_last_error().

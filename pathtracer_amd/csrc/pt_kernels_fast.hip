@@ -537,21 +537,37 @@ PTD V3 sphere_point(float u1, float u2) {            // bsdf.h:29-36; v_sin/v_co
     return v3(r * __builtin_amdgcn_cosf(u2), r * __builtin_amdgcn_sinf(u2), z);
 }
 
-PTD float fresnel_ratio(V3 dir, V3 nrm, float f0, float n1, float n2) {   // bsdf.h:48-69 with f90 = 1
+PTD float fresnel_schlick(float n1, float n2, float c) {                 // bsdf.h:48-51
+    const float q = (n1 - n2) * rcp(n1 + n2);
+    const float r0 = q * q;
+    const float m = 1.0f - c;
+    const float m2 = m * m;
+    return __builtin_fmaf(1.0f - r0, m2 * m2 * m, r0);
+}
+
+// bsdf.h:53-69.  tracePath passes f90 = 1 (bsdf.h:113), for which the last line is lerp(f0, 1, fr) = (1 - fr)*f0 + fr.
+PTD float fresnel_ratio(V3 dir, V3 nrm, float f0, float f90, float n1, float n2) {
     float cX = -dot(dir, nrm);
     if (n1 > n2) {
         const float n = n1 * rcp(n2);
         const float s2 = n * n * __builtin_fmaf(-cX, cX, 1.0f);
-        if (s2 > 1.0f) return 1.0f;
+        if (s2 > 1.0f) return f90;
         cX = fsqrt(1.0f - s2);
     }
-    const float q = (n1 - n2) * rcp(n1 + n2);
-    const float r0 = q * q;
-    const float m = 1.0f - cX;
-    const float m2 = m * m;
-    const float fr = __builtin_fmaf(1.0f - r0, m2 * m2 * m, r0);
-    return __builtin_fmaf(1.0f - fr, f0, fr);          // lerp(f0, 1, fr)
+    const float fr = fresnel_schlick(n1, n2, cX);
+    return __builtin_fmaf(1.0f - fr, f0, fr * f90);
 }
+
+PTD V3 reflect(V3 v, V3 n) { return madd(n, -2.0f * dot(v, n), v); }      // vec_math.h:19-21
+// vec_math.h:23-30: the zero vector on total reflection (k < 0)
+PTD V3 refract(V3 I, V3 N, float eta) {
+    const float ndi = dot(N, I);
+    const float k = __builtin_fmaf(-eta * eta, __builtin_fmaf(-ndi, ndi, 1.0f), 1.0f);
+    V3 r = v3(0.0f, 0.0f, 0.0f);
+    if (!(k < 0.0f)) r = madd(N, -__builtin_fmaf(eta, ndi, fsqrt(k)), I * eta);
+    return r;
+}
+PTD V3 lerp3(V3 v0, V3 v1, float t) { return madd(v1, t, v0 * (1.0f - t)); }   // vec_math.h:10-12
 
 struct Path {
     V3 o, d, coef, contrib;
@@ -584,7 +600,7 @@ PTD bool shade_scatter(Path& p, const Surf& s, const DMat& M, float t, bool hit,
     if (glassy) {
         ior = M.IOR;
         if (f0 > 0.0f) {
-            p_specular = fresnel_ratio(p.d, s.nrm, f0, s.inside ? ior : 1.0f, s.inside ? 1.0f : ior);
+            p_specular = fresnel_ratio(p.d, s.nrm, f0, 1.0f, s.inside ? ior : 1.0f, s.inside ? 1.0f : ior);
             p_refract = transparency * (1.0f - p_specular) * rcp(1.0f - f0);
         }
     }
@@ -602,14 +618,11 @@ PTD bool shade_scatter(Path& p, const Surf& s, const DMat& M, float t, bool hit,
     V3 tint;
     if (mode == 2) {
         const float eta = s.inside ? ior : rcp(ior);
-        const float ndi = dot(s.nrm, p.d);
-        const float k = __builtin_fmaf(-eta * eta, __builtin_fmaf(-ndi, ndi, 1.0f), 1.0f);
-        V3 rd = v3(0.0f, 0.0f, 0.0f);
-        if (!(k < 0.0f)) rd = unit(madd(s.nrm, -__builtin_fmaf(eta, ndi, fsqrt(k)), p.d * eta));
+        V3 rd = unit_or_zero(refract(p.d, s.nrm, eta));          // .normalized() of the zero vector is the zero vector
         const float rr = M.refractionRoughness * M.refractionRoughness;
         if (rr != 0.0f) {
             const V3 hd = unit(s.nrm + sphere_point(rng_u(p.key, slot + 3u), rng_u(p.key, slot + 4u)));
-            rd = unit(madd(hd, rr, rd * (1.0f - rr)));
+            rd = unit(lerp3(rd, hd, rr));
         }
         ndir = rd;
         tint = v3(1.0f, 1.0f, 1.0f);
@@ -620,8 +633,8 @@ PTD bool shade_scatter(Path& p, const Surf& s, const DMat& M, float t, bool hit,
         V3 dd = v3(0.0f, 0.0f, 0.0f);
         if (mode != 1 || sr != 0.0f) dd = unit(s.nrm + sphere_point(rng_u(p.key, slot + 1u), rng_u(p.key, slot + 2u)));
         if (mode == 1) {
-            V3 sd = unit(madd(s.nrm, -2.0f * dot(p.d, s.nrm), p.d));
-            if (sr != 0.0f) sd = unit(madd(dd, sr, sd * (1.0f - sr)));
+            V3 sd = unit(reflect(p.d, s.nrm));
+            if (sr != 0.0f) sd = unit(lerp3(sd, dd, sr));
             ndir = sd;
             tint = v3(M.specularColor[0], M.specularColor[1], M.specularColor[2]);
         } else {
@@ -692,7 +705,7 @@ PTD bool path_shade_alt(Path& p, const Best& b, const FShade* shade, const DMat*
     V3 ndir, w;
     if (M.bsdfType == 1) {
         const float ior = M.IOR;
-        float pr = fresnel_ratio(p.d, s.nrm, M.f0, s.inside ? ior : 1.0f, s.inside ? ior : 1.0f);
+        float pr = fresnel_ratio(p.d, s.nrm, M.f0, 1.0f, s.inside ? ior : 1.0f, s.inside ? ior : 1.0f);
         float pt = 1.0f - pr;
         pr = M.f0 > 0.0f ? pr : 0.0f;
         pt = M.transparency > 0.0f ? pt : 0.0f;
@@ -1454,6 +1467,36 @@ int ptk_render_fast(const RenderArgs& a, int variant, hipStream_t s) {
             else hipLaunchKernelGGL((render_fast_kernel<false, 0, false>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
         }
     }
+    PT_CHECK(hipGetLastError());
+    return 0;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void bsdf_fast_kernel(int fn, const float* __restrict__ in, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 r = v3(0.0f, 0.0f, 0.0f);
+    switch (fn) {
+        case PT_FN_SAMPLE_HEMISPHERE: r = sphere_point(in[2 * i], in[2 * i + 1]); break;
+        case PT_FN_FRESNEL_SCHLICK: out[i] = ptf::fresnel_schlick(in[3 * i], in[3 * i + 1], in[3 * i + 2]); return;
+        case PT_FN_FRESNEL_RATIO: {
+            // getFresnelRatio(N, I, ...) only uses N.I, so the argument order of tracePath's call (direction first) does not matter
+            const float* a = in + 10 * i;
+            out[i] = ptf::fresnel_ratio(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), a[6], a[7], a[8], a[9]);
+            return;
+        }
+        case PT_FN_REFLECT: { const float* a = in + 6 * i; r = ptf::reflect(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5])); break; }
+        case PT_FN_REFRACT: { const float* a = in + 7 * i; r = ptf::refract(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), a[6]); break; }
+        case PT_FN_LERP: { const float* a = in + 7 * i; r = ptf::lerp3(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), a[6]); break; }
+        default: r = unit_or_zero(v3(in[3 * i], in[3 * i + 1], in[3 * i + 2])); break;
+    }
+    out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+}
+}  // namespace
+
+int ptk_bsdf_batch_fast(int fn, const float* in, int n, float* out, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(bsdf_fast_kernel, dim3((n + 255) / 256), dim3(256), 0, s, fn, in, n, out);
     PT_CHECK(hipGetLastError());
     return 0;
 }

@@ -160,6 +160,32 @@ int ptk_trace_paths_parity(const pt_scene* sc, const float* o, const float* d, c
     return 0;
 }
 
+__global__ __launch_bounds__(256) void bsdf_parity_kernel(int fn, const float* __restrict__ in, int n, float* __restrict__ out) {
+    using namespace ptp;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    switch (fn) {
+        case PT_FN_SAMPLE_HEMISPHERE: { const V3 r = sample_hemisphere(in[2 * i], in[2 * i + 1]); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; break; }
+        case PT_FN_FRESNEL_SCHLICK: out[i] = fresnel_schlick(in[3 * i], in[3 * i + 1], in[3 * i + 2]); break;
+        case PT_FN_FRESNEL_RATIO: {
+            const float* a = in + 10 * i;
+            out[i] = fresnel_ratio(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), a[6], a[7], a[8], a[9]);
+            break;
+        }
+        case PT_FN_REFLECT: { const float* a = in + 6 * i; const V3 r = reflect(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5])); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; break; }
+        case PT_FN_REFRACT: { const float* a = in + 7 * i; const V3 r = refract(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), a[6]); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; break; }
+        case PT_FN_LERP: { const float* a = in + 7 * i; const V3 r = lerp3(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), a[6]); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; break; }
+        default: { const V3 r = normalized(v3(in[3 * i], in[3 * i + 1], in[3 * i + 2])); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; break; }
+    }
+}
+
+int ptk_bsdf_batch_parity(int fn, const float* in, int n, float* out, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(bsdf_parity_kernel, dim3((n + 255) / 256), dim3(256), 0, s, fn, in, n, out);
+    PT_CHECK(hipGetLastError());
+    return 0;
+}
+
 int ptk_rng_draws(uint32_t seed_hash, uint32_t pixel, uint32_t sample, int n_slots, uint32_t* bits, float* u, hipStream_t s) {
     if (n_slots <= 0) return 0;
     hipLaunchKernelGGL(rng_kernel, dim3((n_slots + 63) / 64), dim3(64), 0, s, seed_hash, pixel, sample, n_slots, bits, u);

@@ -189,6 +189,19 @@ def raypath(prim, o, d, filter=True):
     return out
 
 
+BSDF_ARITY = {0: (2, 3), 1: (3, 1), 2: (10, 1), 3: (6, 3), 4: (7, 3), 5: (7, 3), 6: (3, 3)}
+
+
+def bsdf_batch(fn, x):
+    """sampleHemisphere / FresnelSchlick / getFresnelRatio / reflect / refract / lerp / normalized on rows of x."""
+    n_in, n_out = BSDF_ARITY[fn]
+    x = np.ascontiguousarray(x, np.float32).reshape(-1, n_in)
+    out = np.zeros((x.shape[0], n_out), np.float32)
+    rc = lib().oracle_bsdf_batch(C.c_int(fn), _fp(x), C.c_int(x.shape[0]), _fp(out))
+    assert rc == 0
+    return out
+
+
 def rng(seed, pixel, sample, n_slots):
     bits = np.zeros(n_slots, np.uint32); u = np.zeros(n_slots, np.float32)
     lib().oracle_rng(C.c_uint(seed), C.c_uint(pixel), C.c_uint(sample), C.c_int(n_slots), _fp(bits), _fp(u))

@@ -45,6 +45,18 @@ CLASSES_BSDF = {"fast_bad_pixel_frac": 0.02, "fast_mean_rel": 0.03}   # bsdf_alt
 PARITY_SMALL_FRAME_RMSE = 1e-5                         # parity-order kernel on frames of a few thousand pixels (measured 5e-9)
 
 
+# pt_bsdf_batch: largest error of each helper function against the oracle over 65 536 random arguments, in units of
+# the float spacing at the result's largest component.  Parity-order code is bit-exact except where it calls the
+# device's sinf/cosf.  Fast code, measured: sampleHemisphere 10.5 (v_sin/v_cos in revolutions), FresnelSchlick 4,
+# reflect 5, lerp 4, normalized 3 (v_rsq); getFresnelRatio 228 and refract 202 are reached only within rounding of the
+# critical angle, where sqrt(1 - s2) and sqrt(k) amplify any error (mean error 0.6 and 0.2).
+BSDF_ULP = {
+    "parity": {"sampleHemisphere": 2, "FresnelSchlick": 0, "getFresnelRatio": 0, "reflect": 0, "refract": 0, "lerp": 0, "normalized": 0},
+    "fast": {"sampleHemisphere": 16, "FresnelSchlick": 8, "getFresnelRatio": 512, "reflect": 8, "refract": 512, "lerp": 8, "normalized": 4},
+}
+BSDF_FAST_MEAN_ULP = 1.0     # mean error of every fast helper function
+
+
 def fast_image_rmse(spp):
     """Bound on the fast kernel's image RMSE against the oracle at `spp` samples per pixel, same seed."""
     return FAST["image_rmse_at_1spp"] / float(spp) ** 0.5
