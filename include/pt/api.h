@@ -12,7 +12,11 @@
 // bounds, material); getRayPath / getIntersections / getNearestIntersection /
 // tracePath / render marshal their arguments into the C ABI of pt_hip.h and run
 // the gfx950 kernels of libpt_hip.so.  The one-ray forms exist for drop-in
-// compatibility and cost a kernel launch each; the *_batch forms take arrays.
+// compatibility and cost one launch and two copies each (tens of microseconds):
+// the device copy of the scene they name is kept from call to call (looked up
+// by the shapes' contents, so a changed shape or material uploads anew) and
+// all staging goes through one buffer per host thread that is allocated once.
+// The *_batch forms take arrays.
 // `ray&` parameters are `const ray&` (the reference binds temporaries to
 // non-const references, shapes.h:61, which g++ and clang++ reject).
 //
@@ -100,16 +104,38 @@ inline pt_material to_abi(const Material& m) {
     return r;
 }
 
-// Device array that frees itself.
-template <typename T> struct DeviceBuffer {
-    T* p = nullptr;
-    size_t n = 0;
-    explicit DeviceBuffer(size_t count) : n(count) { if (n) checkHipErrors(hipMalloc((void**)&p, n * sizeof(T))); }
-    DeviceBuffer(const T* host, size_t count) : DeviceBuffer(count) { if (n) checkHipErrors(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice)); }
-    ~DeviceBuffer() { if (p) (void)hipFree(p); }
-    DeviceBuffer(const DeviceBuffer&) = delete;
-    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
-    void to_host(T* host) const { if (n) checkHipErrors(hipMemcpy(host, p, n * sizeof(T), hipMemcpyDeviceToHost)); }
+// Staging memory of the calls below: one device buffer and one pinned host buffer per host thread, grown to the
+// largest request so far and kept (pt::release_cached() frees them).  A call packs its inputs at the front and reads
+// its outputs behind them: one copy in, the launch, one copy out.
+struct Staging {
+    char* dev = nullptr;
+    char* host = nullptr;
+    size_t cap = 0;
+    void reserve(size_t bytes) {
+        if (bytes <= cap) return;
+        release();
+        size_t want = 1 << 16;
+        while (want < bytes) want <<= 1;
+        checkHipErrors(hipMalloc((void**)&dev, want));
+        checkHipErrors(hipHostMalloc((void**)&host, want, hipHostMallocDefault));
+        cap = want;
+    }
+    void release() {
+        if (dev) (void)hipFree(dev);
+        if (host) (void)hipHostFree(host);
+        dev = nullptr; host = nullptr; cap = 0;
+    }
+};
+inline Staging& staging() { static thread_local Staging s; return s; }
+
+// Carves arrays out of the staging buffers, device and host side by side.
+struct Carver {
+    Staging& st;
+    size_t at = 0;
+    explicit Carver(Staging& s) : st(s) {}
+    template <typename T> size_t take(size_t count) { const size_t off = at; at += (count * sizeof(T) + 15) / 16 * 16; return off; }
+    template <typename T> T* dev(size_t off) const { return reinterpret_cast<T*>(st.dev + off); }
+    template <typename T> T* host(size_t off) const { return reinterpret_cast<T*>(st.host + off); }
 };
 
 // A scene on one device: what constructScene + the Shape** array are in the
@@ -125,6 +151,46 @@ class DeviceScene {
     pt_scene* handle() const { return h; }
     const pt_material& material(int i) const { return mats[i]; }
 };
+
+// The tables a Shape* array flattens to: what pt_scene_upload takes, and the key under which uploads are kept.
+struct SceneTables {
+    std::vector<pt_prim> prims;
+    std::vector<pt_material> mats;
+    bool operator==(const SceneTables& o) const {
+        return prims.size() == o.prims.size() && mats.size() == o.mats.size() &&
+               std::memcmp(prims.data(), o.prims.data(), prims.size() * sizeof(pt_prim)) == 0 &&
+               std::memcmp(mats.data(), o.mats.data(), mats.size() * sizeof(pt_material)) == 0;
+    }
+};
+SceneTables flatten(Shape* const* scene, int n_objects);
+
+// Uploaded scenes of the one-ray calls, per host thread: found again by content (so mutating a shape or its material
+// between calls simply misses), the least recently used of more than eight is freed.
+struct SceneCache {
+    struct Entry { SceneTables key; int device; pt_scene* h; unsigned long long used; };
+    std::vector<Entry> entries;
+    unsigned long long clock = 0;
+    pt_scene* get(Shape* const* scene, int n_objects, int device = 0) {
+        SceneTables key = flatten(scene, n_objects);
+        for (Entry& e : entries)
+            if (e.device == device && e.key == key) { e.used = ++clock; return e.h; }
+        if (entries.size() >= 8) {
+            size_t lru = 0;
+            for (size_t k = 1; k < entries.size(); k++) if (entries[k].used < entries[lru].used) lru = k;
+            pt_scene_free(entries[lru].h);
+            entries.erase(entries.begin() + (long)lru);
+        }
+        pt_scene* h = nullptr;
+        checkHipErrors(pt_scene_upload(key.prims.data(), n_objects, key.mats.data(), (int)key.mats.size(), device, &h));
+        entries.push_back(Entry{std::move(key), device, h, ++clock});
+        return h;
+    }
+    void clear() { for (Entry& e : entries) pt_scene_free(e.h); entries.clear(); }
+};
+inline SceneCache& scene_cache() { static thread_local SceneCache c; return c; }
+
+// Frees this thread's staging buffers and cached scenes (they are otherwise kept until the process ends).
+inline void release_cached() { staging().release(); scene_cache().clear(); }
 
 }  // namespace pt
 
@@ -182,46 +248,58 @@ class Sphere : public Shape {
     Sphere(Material material, Affine3f transform) : Shape(PT_SPHERE, transform) { this->material = material; }
 };
 
-inline pt::DeviceScene::DeviceScene(Shape* const* scene, int n_objects, int device) {
-    std::vector<pt_prim> prims((size_t)n_objects);
+inline pt::SceneTables pt::flatten(Shape* const* scene, int n_objects) {
+    SceneTables t;
+    t.prims.resize((size_t)n_objects);
     for (int k = 0; k < n_objects; k++) {
-        prims[k] = scene[k]->description();
+        t.prims[k] = scene[k]->description();
         // shapes own their Material by value (shapes.h:41); identical ones share a table slot
         const pt_material m = pt::to_abi(scene[k]->material);
         size_t slot = 0;
-        while (slot < mats.size() && std::memcmp(&mats[slot], &m, sizeof(m)) != 0) slot++;
-        if (slot == mats.size()) mats.push_back(m);
-        prims[k].material = (int32_t)slot;
+        while (slot < t.mats.size() && std::memcmp(&t.mats[slot], &m, sizeof(m)) != 0) slot++;
+        if (slot == t.mats.size()) t.mats.push_back(m);
+        t.prims[k].material = (int32_t)slot;
     }
-    checkHipErrors(pt_scene_upload(prims.data(), n_objects, mats.data(), (int)mats.size(), device, &h));
+    return t;
 }
+
+inline pt::DeviceScene::DeviceScene(Shape* const* scene, int n_objects, int device) {
+    SceneTables t = flatten(scene, n_objects);
+    mats = t.mats;
+    checkHipErrors(pt_scene_upload(t.prims.data(), n_objects, mats.data(), (int)mats.size(), device, &h));
+}
+
+namespace pt {
+inline void pack_rays(const ray* rays, int n, float* o, float* d) {
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) { o[3 * i + k] = rays[i].origin()[k]; d[3 * i + k] = rays[i].direction()[k]; }
+}
+inline vec3 vec3_at(const float* p, int i) { return vec3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+}  // namespace pt
 
 inline void Shape::getIntersections_batch(const ray* rays, int n, RayPath* out, int filter) const {
     if (n <= 0) return;
     Shape* self = const_cast<Shape*>(this);
-    pt::DeviceScene sc(&self, 1);
-    std::vector<float> o((size_t)n * 3), d((size_t)n * 3);
-    for (int i = 0; i < n; i++)
-        for (int k = 0; k < 3; k++) { o[3 * i + k] = rays[i].origin()[k]; d[3 * i + k] = rays[i].direction()[k]; }
-    pt::DeviceBuffer<float> d_o(o.data(), o.size()), d_d(d.data(), d.size());
-    pt::DeviceBuffer<int32_t> d_n(n), d_h1(n), d_h2(n);
-    pt::DeviceBuffer<float> d_t1(n), d_t2(n), d_p1((size_t)n * 3), d_p2((size_t)n * 3), d_n1((size_t)n * 3), d_n2((size_t)n * 3);
-    checkHipErrors(pt_raypath_batch(sc.handle(), 0, d_o.p, d_d.p, n, filter, d_n.p, d_h1.p, d_t1.p, d_p1.p, d_n1.p,
-                                    d_h2.p, d_t2.p, d_p2.p, d_n2.p, nullptr));
-    checkHipErrors(hipDeviceSynchronize());
-    std::vector<int32_t> hn(n), h1(n), h2(n);
-    std::vector<float> t1(n), t2(n), p1((size_t)n * 3), p2((size_t)n * 3), n1((size_t)n * 3), n2((size_t)n * 3);
-    d_n.to_host(hn.data()); d_h1.to_host(h1.data()); d_h2.to_host(h2.data());
-    d_t1.to_host(t1.data()); d_t2.to_host(t2.data());
-    d_p1.to_host(p1.data()); d_p2.to_host(p2.data()); d_n1.to_host(n1.data()); d_n2.to_host(n2.data());
+    pt_scene* sc = pt::scene_cache().get(&self, 1);
+    const size_t N = (size_t)n;
+    pt::Carver c(pt::staging());
+    const size_t o = c.take<float>(3 * N), d = c.take<float>(3 * N), in_end = c.at;
+    const size_t cnt = c.take<int32_t>(N), h1 = c.take<int32_t>(N), h2 = c.take<int32_t>(N), t1 = c.take<float>(N), t2 = c.take<float>(N);
+    const size_t p1 = c.take<float>(3 * N), p2 = c.take<float>(3 * N), n1 = c.take<float>(3 * N), n2 = c.take<float>(3 * N);
+    c.st.reserve(c.at);
+    pt::pack_rays(rays, n, c.host<float>(o), c.host<float>(d));
+    checkHipErrors(hipMemcpy(c.st.dev, c.st.host, in_end, hipMemcpyHostToDevice));
+    checkHipErrors(pt_raypath_batch(sc, 0, c.dev<float>(o), c.dev<float>(d), n, filter, c.dev<int32_t>(cnt), c.dev<int32_t>(h1), c.dev<float>(t1),
+                                    c.dev<float>(p1), c.dev<float>(n1), c.dev<int32_t>(h2), c.dev<float>(t2), c.dev<float>(p2), c.dev<float>(n2), nullptr));
+    checkHipErrors(hipMemcpy(c.st.host + in_end, c.st.dev + in_end, c.at - in_end, hipMemcpyDeviceToHost));   // waits for the kernel
     for (int i = 0; i < n; i++) {
         RayPath& rp = out[i];
         rp = RayPath();
-        rp.n_intersections = hn[i];
-        rp.first.intersects = h1[i] != 0; rp.first.distance = t1[i]; rp.first.material = material;
-        rp.first.position = vec3(p1[3 * i], p1[3 * i + 1], p1[3 * i + 2]); rp.first.normal = vec3(n1[3 * i], n1[3 * i + 1], n1[3 * i + 2]);
-        rp.second.intersects = h2[i] != 0; rp.second.distance = t2[i]; rp.second.material = material;
-        rp.second.position = vec3(p2[3 * i], p2[3 * i + 1], p2[3 * i + 2]); rp.second.normal = vec3(n2[3 * i], n2[3 * i + 1], n2[3 * i + 2]);
+        rp.n_intersections = c.host<int32_t>(cnt)[i];
+        rp.first.intersects = c.host<int32_t>(h1)[i] != 0; rp.first.distance = c.host<float>(t1)[i]; rp.first.material = material;
+        rp.first.position = pt::vec3_at(c.host<float>(p1), i); rp.first.normal = pt::vec3_at(c.host<float>(n1), i);
+        rp.second.intersects = c.host<int32_t>(h2)[i] != 0; rp.second.distance = c.host<float>(t2)[i]; rp.second.material = material;
+        rp.second.position = pt::vec3_at(c.host<float>(p2), i); rp.second.normal = pt::vec3_at(c.host<float>(n2), i);
     }
 }
 
@@ -232,75 +310,81 @@ inline RayPath Shape::query(const ray& r, int filter) const {
 }
 
 // shapes.h:79-100 for n rays against an uploaded scene.
-inline void getNearestIntersection_batch(const ray* rays, int n, const pt::DeviceScene& sc, Shape* const* scene, IntersectionPoint* out) {
+inline void pt_nearest_rays(const ray* rays, int n, pt_scene* sc, Shape* const* scene, IntersectionPoint* out) {
     if (n <= 0) return;
-    std::vector<float> o((size_t)n * 3), d((size_t)n * 3);
-    for (int i = 0; i < n; i++)
-        for (int k = 0; k < 3; k++) { o[3 * i + k] = rays[i].origin()[k]; d[3 * i + k] = rays[i].direction()[k]; }
-    pt::DeviceBuffer<float> d_o(o.data(), o.size()), d_d(d.data(), d.size()), d_t(n), d_p((size_t)n * 3), d_nr((size_t)n * 3);
-    pt::DeviceBuffer<int32_t> d_prim(n), d_in(n);
-    checkHipErrors(pt_nearest_batch(sc.handle(), d_o.p, d_d.p, n, d_prim.p, d_t.p, d_p.p, d_nr.p, d_in.p, nullptr));
-    checkHipErrors(hipDeviceSynchronize());
-    std::vector<int32_t> prim(n), in(n);
-    std::vector<float> t(n), p((size_t)n * 3), nr((size_t)n * 3);
-    d_prim.to_host(prim.data()); d_in.to_host(in.data()); d_t.to_host(t.data()); d_p.to_host(p.data()); d_nr.to_host(nr.data());
+    const size_t N = (size_t)n;
+    pt::Carver c(pt::staging());
+    const size_t o = c.take<float>(3 * N), d = c.take<float>(3 * N), in_end = c.at;
+    const size_t prim = c.take<int32_t>(N), in = c.take<int32_t>(N), t = c.take<float>(N), p = c.take<float>(3 * N), nr = c.take<float>(3 * N);
+    c.st.reserve(c.at);
+    pt::pack_rays(rays, n, c.host<float>(o), c.host<float>(d));
+    checkHipErrors(hipMemcpy(c.st.dev, c.st.host, in_end, hipMemcpyHostToDevice));
+    checkHipErrors(pt_nearest_batch(sc, c.dev<float>(o), c.dev<float>(d), n, c.dev<int32_t>(prim), c.dev<float>(t), c.dev<float>(p), c.dev<float>(nr),
+                                    c.dev<int32_t>(in), nullptr));
+    checkHipErrors(hipMemcpy(c.st.host + in_end, c.st.dev + in_end, c.at - in_end, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; i++) {
         IntersectionPoint& ip = out[i];
         ip = IntersectionPoint();
-        ip.intersects = prim[i] >= 0;
+        const int32_t k = c.host<int32_t>(prim)[i];
+        ip.intersects = k >= 0;
         if (!ip.intersects) continue;
-        ip.distance = t[i];
-        ip.material = scene[prim[i]]->material;
-        ip.position = vec3(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
-        ip.normal = vec3(nr[3 * i], nr[3 * i + 1], nr[3 * i + 2]);
-        ip.inside = in[i] != 0;
+        ip.distance = c.host<float>(t)[i];
+        ip.material = scene[k]->material;
+        ip.position = pt::vec3_at(c.host<float>(p), i);
+        ip.normal = pt::vec3_at(c.host<float>(nr), i);
+        ip.inside = c.host<int32_t>(in)[i] != 0;
     }
+}
+inline void getNearestIntersection_batch(const ray* rays, int n, const pt::DeviceScene& sc, Shape* const* scene, IntersectionPoint* out) {
+    pt_nearest_rays(rays, n, sc.handle(), scene, out);
 }
 
 // shapes.h:79 — one ray, scene given as the reference's Shape** array.
 inline IntersectionPoint getNearestIntersection(const ray& r, Shape** scene, int n_objects) {
-    pt::DeviceScene sc(scene, n_objects);
     IntersectionPoint ip;
-    getNearestIntersection_batch(&r, 1, sc, scene, &ip);
+    pt_nearest_rays(&r, 1, pt::scene_cache().get(scene, n_objects), scene, &ip);
     return ip;
 }
 
 // bsdf.h:73-168 for n rays; ray i draws from stream s[i] starting after the two
 // camera-jitter slots.  n_bounces defaults to the reference's literal (bsdf.h:75).
-inline void tracePath_batch(const pt::DeviceScene& sc, const ray* rays, const pt_rng* s, int n, vec3* out,
-                            int n_bounces = 5, int math_mode = PT_MATH_PARITY, int bsdf_model = PT_BSDF_REFERENCE) {
+// end (optional): the ray each call of the reference's tracePath leaves in its `ray& r` argument (bsdf.h:165).
+inline void pt_trace_rays(pt_scene* sc, const ray* rays, const pt_rng* s, int n, vec3* out, ray* end, int n_bounces, int math_mode, int bsdf_model) {
     if (n <= 0) return;
-    std::vector<float> o((size_t)n * 3), d((size_t)n * 3);
-    std::vector<uint32_t> px(n), sm(n);
+    const size_t N = (size_t)n;
+    pt::Carver c(pt::staging());
+    const size_t o = c.take<float>(3 * N), d = c.take<float>(3 * N), px = c.take<uint32_t>(N), sm = c.take<uint32_t>(N), in_end = c.at;
+    const size_t rgb = c.take<float>(3 * N), eo = c.take<float>(3 * N), ed = c.take<float>(3 * N);
+    c.st.reserve(c.at);
+    pt::pack_rays(rays, n, c.host<float>(o), c.host<float>(d));
+    for (int i = 0; i < n; i++) { c.host<uint32_t>(px)[i] = s[i].pixel; c.host<uint32_t>(sm)[i] = s[i].sample; }
+    checkHipErrors(hipMemcpy(c.st.dev, c.st.host, in_end, hipMemcpyHostToDevice));
+    checkHipErrors(pt_trace_paths_end(sc, c.dev<float>(o), c.dev<float>(d), c.dev<uint32_t>(px), c.dev<uint32_t>(sm), n, s[0].seed, n_bounces, math_mode,
+                                      bsdf_model, c.dev<float>(rgb), c.dev<float>(eo), c.dev<float>(ed), nullptr));
+    checkHipErrors(hipMemcpy(c.st.host + in_end, c.st.dev + in_end, c.at - in_end, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; i++) {
-        for (int k = 0; k < 3; k++) { o[3 * i + k] = rays[i].origin()[k]; d[3 * i + k] = rays[i].direction()[k]; }
-        px[i] = s[i].pixel; sm[i] = s[i].sample;
+        out[i] = pt::vec3_at(c.host<float>(rgb), i);
+        if (end) end[i] = ray(pt::vec3_at(c.host<float>(eo), i), pt::vec3_at(c.host<float>(ed), i));
     }
-    pt::DeviceBuffer<float> d_o(o.data(), o.size()), d_d(d.data(), d.size()), d_rgb((size_t)n * 3);
-    pt::DeviceBuffer<uint32_t> d_px(px.data(), px.size()), d_sm(sm.data(), sm.size());
-    if (bsdf_model == PT_BSDF_CLASSES)
-        checkHipErrors(pt_trace_paths_alt(sc.handle(), d_o.p, d_d.p, d_px.p, d_sm.p, n, s[0].seed, n_bounces, math_mode, d_rgb.p, nullptr));
-    else
-        checkHipErrors(pt_trace_paths(sc.handle(), d_o.p, d_d.p, d_px.p, d_sm.p, n, s[0].seed, n_bounces, math_mode, d_rgb.p, nullptr));
-    checkHipErrors(hipDeviceSynchronize());
-    std::vector<float> rgb((size_t)n * 3);
-    d_rgb.to_host(rgb.data());
-    for (int i = 0; i < n; i++) out[i] = vec3(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+}
+inline void tracePath_batch(const pt::DeviceScene& sc, const ray* rays, const pt_rng* s, int n, vec3* out,
+                            int n_bounces = 5, int math_mode = PT_MATH_PARITY, int bsdf_model = PT_BSDF_REFERENCE, ray* end = nullptr) {
+    pt_trace_rays(sc.handle(), rays, s, n, out, end, n_bounces, math_mode, bsdf_model);
 }
 
-// bsdf.h:73 — the reference signature.  The reference mutates `r` as the path
-// advances and returns the radiance; only the radiance is observable to callers
-// (main.cu:65), so `r` is left as passed.
+// bsdf.h:73 — the reference signature: returns the radiance and, like the reference, leaves in `r` the last ray the
+// path assigned (bsdf.h:165).
 // A host that includes bsdf_alternative.h instead of bsdf.h gets that file's tracePath (:153-219) under the same
 // name; here that choice is the macro PT_USE_BSDF_ALTERNATIVE, defined before this header is included.
 inline vec3 tracePath(Shape** scene, int n_objects, ray& r, pt_rng* s, int n_bounces = 5) {
-    pt::DeviceScene sc(scene, n_objects);
     vec3 out;
+    ray end;
 #ifdef PT_USE_BSDF_ALTERNATIVE
-    tracePath_batch(sc, &r, s, 1, &out, n_bounces, PT_MATH_PARITY, PT_BSDF_CLASSES);
+    pt_trace_rays(pt::scene_cache().get(scene, n_objects), &r, s, 1, &out, &end, n_bounces, PT_MATH_PARITY, PT_BSDF_CLASSES);
 #else
-    tracePath_batch(sc, &r, s, 1, &out, n_bounces);
+    pt_trace_rays(pt::scene_cache().get(scene, n_objects), &r, s, 1, &out, &end, n_bounces, PT_MATH_PARITY, PT_BSDF_REFERENCE);
 #endif
+    r = end;
     return out;
 }
 

@@ -61,6 +61,42 @@ struct Matrix3f {
     float m[3][3];
 };
 
+// vec4, matrix4 and Q4 (vec_math.h:15-17) are declared by the reference and used nowhere in it; they are here as
+// plain value types under the same names so that code which mentions them keeps compiling.
+struct vec4 {
+    float v[4];
+    vec4() : v{0.0f, 0.0f, 0.0f, 0.0f} {}
+    vec4(float x, float y, float z, float w) : v{x, y, z, w} {}
+    float x() const { return v[0]; }
+    float y() const { return v[1]; }
+    float z() const { return v[2]; }
+    float w() const { return v[3]; }
+    float operator[](int i) const { return v[i]; }
+    float& operator[](int i) { return v[i]; }
+    float dot(const vec4& o) const { return (v[0] * o.v[0] + v[1] * o.v[1]) + (v[2] * o.v[2] + v[3] * o.v[3]); }
+};
+struct matrix4 {
+    float m[4][4];
+    static matrix4 Identity() { matrix4 r; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) r.m[i][j] = i == j ? 1.0f : 0.0f; return r; }
+    float operator()(int i, int j) const { return m[i][j]; }
+    float& operator()(int i, int j) { return m[i][j]; }
+    vec4 operator*(const vec4& p) const {
+        vec4 r;
+        for (int i = 0; i < 4; i++) r.v[i] = (m[i][0] * p.v[0] + m[i][1] * p.v[1]) + (m[i][2] * p.v[2] + m[i][3] * p.v[3]);
+        return r;
+    }
+};
+struct Q4 {                                    // Eigen::Quaternion<float>: (w, x, y, z)
+    float qw, qx, qy, qz;
+    Q4() : qw(1.0f), qx(0.0f), qy(0.0f), qz(0.0f) {}
+    Q4(float w, float x, float y, float z) : qw(w), qx(x), qy(y), qz(z) {}
+    float w() const { return qw; }
+    float x() const { return qx; }
+    float y() const { return qy; }
+    float z() const { return qz; }
+    static Q4 Identity() { return Q4(); }
+};
+
 // Eigen::AngleAxisf(angle, axis).toRotationMatrix()
 struct AngleAxisf {
     float angle;

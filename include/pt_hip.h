@@ -195,6 +195,14 @@ int pt_trace_paths_alt(const pt_scene* scene, const float* d_o, const float* d_d
                        const uint32_t* d_sample, int n_rays, uint32_t seed, int n_bounces, int math_mode,
                        float* d_rgb, void* stream);
 
+/* tracePath of either file with its side effect: the reference takes `ray& r` and leaves in it the last ray it
+ * assigned (bsdf.h:165 / bsdf_alternative.h:215) — the ray of the segment on which the path ended (miss, roulette),
+ * or the ray after the last bounce when the path ran out of bounces.  d_end_o, d_end_d: [n_rays][3], either may be
+ * NULL.  bsdf_model: PT_BSDF_REFERENCE or PT_BSDF_CLASSES. */
+int pt_trace_paths_end(const pt_scene* scene, const float* d_o, const float* d_d, const uint32_t* d_pixel,
+                       const uint32_t* d_sample, int n_rays, uint32_t seed, int n_bounces, int math_mode, int bsdf_model,
+                       float* d_rgb, float* d_end_o, float* d_end_d, void* stream);
+
 /* The helper functions of bsdf.h and vec_math.h on arrays, one element per thread, in either family of kernels:
  * what tracePath calls per segment, reachable on its own (the reference has no such entry point: they are
  * __device__ functions).  d_in: [n][n_in] floats, d_out: [n][n_out] floats, both on `device`.

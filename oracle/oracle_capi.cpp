@@ -271,6 +271,20 @@ void oracle_trace_paths_alt(void* scene, const float* o, const float* d, const u
     }
 }
 
+// tracePath with its side effect on `r` (bsdf.h:165, bsdf_alternative.h:215): radiance plus the ray left in r.
+void oracle_trace_paths_end(void* scene, const float* o, const float* d, const unsigned* pixel, const unsigned* sample,
+                            int n_rays, unsigned seed, int n_bounces, int bsdf_model, float* rgb, float* end_o, float* end_d) {
+    Scene* sc = static_cast<Scene*>(scene);
+    for (int i = 0; i < n_rays; i++) {
+        ray r(vec3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), vec3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
+        pt_rng s = rng_init(seed, pixel[i], sample[i]);
+        s.slot = 2;
+        vec3 c = bsdf_model == 1 ? tracePathAlternative(sc->ptrs.data(), (int)sc->ptrs.size(), r, &s, n_bounces)
+                                 : tracePath(sc->ptrs.data(), (int)sc->ptrs.size(), r, &s, n_bounces);
+        for (int k = 0; k < 3; k++) { rgb[3 * i + k] = c[k]; end_o[3 * i + k] = r.origin()[k]; end_d[3 * i + k] = r.direction()[k]; }
+    }
+}
+
 // Raw RNG access: bits and uniforms of draw slots [0, n_slots) of one stream.
 // The helper functions of bsdf.h / vec_math.h on arrays; fn and the array shapes as pt_bsdf_batch of the product's ABI:
 // 0 sampleHemisphere (2 -> 3), 1 FresnelSchlick (3 -> 1), 2 getFresnelRatio (10 -> 1), 3 reflect (6 -> 3),

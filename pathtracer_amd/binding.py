@@ -80,6 +80,7 @@ def _load():
     L.pt_nearest_batch.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.pt_trace_paths.argtypes = [vp, vp, vp, vp, vp, i32, u32, i32, i32, vp, vp]
     L.pt_trace_paths_alt.argtypes = [vp, vp, vp, vp, vp, i32, u32, i32, i32, vp, vp]
+    L.pt_trace_paths_end.argtypes = [vp, vp, vp, vp, vp, i32, u32, i32, i32, i32, vp, vp, vp, vp]
     L.pt_rng_draws.argtypes = [i32, u32, u32, u32, i32, vp, vp, vp]
     L.pt_bsdf_batch.argtypes = [i32, i32, i32, vp, i32, vp, vp]
     L.pt_bsdf_arity.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
@@ -108,7 +109,7 @@ lib = _load()
 EXPORTS = [
     "pt_scene_upload", "pt_scene_upload_opt", "pt_scene_tune", "pt_scene_free", "pt_scene_device", "pt_scene_bvh_nodes", "pt_default_scene", "pt_glass_grid_scene",
     "pt_synthetic_scene", "pt_focal_length", "pt_render", "pt_raypath_batch", "pt_nearest_batch",
-    "pt_trace_paths", "pt_trace_paths_alt", "pt_rng_draws", "pt_bsdf_batch", "pt_bsdf_arity", "pt_ppm_p3", "pt_last_error", "pt_version",
+    "pt_trace_paths", "pt_trace_paths_alt", "pt_trace_paths_end", "pt_rng_draws", "pt_bsdf_batch", "pt_bsdf_arity", "pt_ppm_p3", "pt_last_error", "pt_version",
     "pt_scene_parse", "pt_ppm_p6", "pt_pfm",
     "pt_tile_rows", "pt_comm_unique_id", "pt_comm_init_rank", "pt_comm_init_all", "pt_comm_free", "pt_comm_rank",
     "pt_comm_world", "pt_gather_framebuffer", "pt_assemble_rows", "pt_gather_framebuffer_noalloc",
@@ -310,6 +311,16 @@ class Scene:
             _check(lib.pt_nearest_batch(self.h, _ptr(o), _ptr(d), n, _ptr(res["prim"]), _ptr(res["t"]),
                                         _ptr(res["pos"]), _ptr(res["nrm"]), _ptr(res["inside"]), _stream()))
         return res
+
+    def trace_paths_end(self, o, d, pixel, sample, seed=0, n_bounces=5, math_mode=PT_MATH_PARITY, bsdf_model=PT_BSDF_REFERENCE):
+        """pt_trace_paths_end: (radiance, origin, direction of the ray tracePath leaves in `r`)."""
+        torch = _torch()
+        n = o.shape[0]
+        rgb, eo, ed = (torch.zeros((n, 3), dtype=torch.float32, device=self._dev()) for _ in range(3))
+        with torch.cuda.device(self.device):
+            _check(lib.pt_trace_paths_end(self.h, _ptr(o), _ptr(d), _ptr(pixel), _ptr(sample), n, seed, n_bounces, math_mode, bsdf_model,
+                                          _ptr(rgb), _ptr(eo), _ptr(ed), _stream()))
+        return rgb, eo, ed
 
     def trace_paths(self, o, d, pixel, sample, seed=0, n_bounces=5, math_mode=PT_MATH_PARITY, bsdf_model=PT_BSDF_REFERENCE):
         torch = _torch()

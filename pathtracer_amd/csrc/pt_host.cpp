@@ -780,15 +780,16 @@ int pt_nearest_batch(const pt_scene* sc, const float* d_o, const float* d_d, int
 
 static int trace_paths(const char* who, const pt_scene* sc, const float* d_o, const float* d_d, const uint32_t* d_pixel,
                        const uint32_t* d_sample, int n_rays, uint32_t seed, int n_bounces, int math_mode, int bsdf_model,
-                       float* d_rgb, void* stream) {
+                       float* d_rgb, float* d_end_o, float* d_end_d, void* stream) {
     if (!sc || !d_o || !d_d || !d_pixel || !d_sample || !d_rgb || n_rays < 0 || n_bounces < 0)
         return pt_set_error(-1, who, __FILE__, __LINE__);
+    if (bsdf_model != PT_BSDF_REFERENCE && bsdf_model != PT_BSDF_CLASSES) return pt_set_error(-1, who, __FILE__, __LINE__);
     PT_CHECK(hipSetDevice(sc->device));
     const uint32_t sh = host_hash(seed + 0x9E3779B9u);
     if (math_mode == PT_MATH_PARITY)
-        return ptk_trace_paths_parity(sc, d_o, d_d, d_pixel, d_sample, n_rays, sh, n_bounces, bsdf_model, d_rgb, (hipStream_t)stream);
+        return ptk_trace_paths_parity(sc, d_o, d_d, d_pixel, d_sample, n_rays, sh, n_bounces, bsdf_model, d_rgb, d_end_o, d_end_d, (hipStream_t)stream);
     if (math_mode == PT_MATH_FAST)
-        return ptk_trace_paths_fast(sc, d_o, d_d, d_pixel, d_sample, n_rays, sh, n_bounces, bsdf_model, d_rgb, (hipStream_t)stream);
+        return ptk_trace_paths_fast(sc, d_o, d_d, d_pixel, d_sample, n_rays, sh, n_bounces, bsdf_model, d_rgb, d_end_o, d_end_d, (hipStream_t)stream);
     return pt_set_error(-1, who, __FILE__, __LINE__);
 }
 
@@ -796,14 +797,21 @@ int pt_trace_paths(const pt_scene* sc, const float* d_o, const float* d_d, const
                    const uint32_t* d_sample, int n_rays, uint32_t seed, int n_bounces, int math_mode,
                    float* d_rgb, void* stream) {
     return trace_paths("pt_trace_paths: bad arguments or unknown math_mode", sc, d_o, d_d, d_pixel, d_sample, n_rays, seed,
-                       n_bounces, math_mode, PT_BSDF_REFERENCE, d_rgb, stream);
+                       n_bounces, math_mode, PT_BSDF_REFERENCE, d_rgb, nullptr, nullptr, stream);
 }
 
 int pt_trace_paths_alt(const pt_scene* sc, const float* d_o, const float* d_d, const uint32_t* d_pixel,
                        const uint32_t* d_sample, int n_rays, uint32_t seed, int n_bounces, int math_mode,
                        float* d_rgb, void* stream) {
     return trace_paths("pt_trace_paths_alt: bad arguments or unknown math_mode", sc, d_o, d_d, d_pixel, d_sample, n_rays, seed,
-                       n_bounces, math_mode, PT_BSDF_CLASSES, d_rgb, stream);
+                       n_bounces, math_mode, PT_BSDF_CLASSES, d_rgb, nullptr, nullptr, stream);
+}
+
+int pt_trace_paths_end(const pt_scene* sc, const float* d_o, const float* d_d, const uint32_t* d_pixel,
+                       const uint32_t* d_sample, int n_rays, uint32_t seed, int n_bounces, int math_mode, int bsdf_model,
+                       float* d_rgb, float* d_end_o, float* d_end_d, void* stream) {
+    return trace_paths("pt_trace_paths_end: bad arguments, unknown math_mode or bsdf_model", sc, d_o, d_d, d_pixel, d_sample, n_rays, seed,
+                       n_bounces, math_mode, bsdf_model, d_rgb, d_end_o, d_end_d, stream);
 }
 
 int pt_bsdf_arity(int fn, int* n_in, int* n_out) {

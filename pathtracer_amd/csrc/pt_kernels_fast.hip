@@ -1401,7 +1401,8 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(SceneRefs sc,
                                                          const FShade* __restrict__ shade, const DMat* __restrict__ mats,
                                                          const float* __restrict__ o, const float* __restrict__ d,
                                                          const uint32_t* __restrict__ pixel, const uint32_t* __restrict__ sample,
-                                                         int n, uint32_t seed_hash, int n_bounces, int bsdf_model, float* rgb) {
+                                                         int n, uint32_t seed_hash, int n_bounces, int bsdf_model, float* rgb,
+                                                         float* end_o, float* end_d) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Path p;
@@ -1410,8 +1411,16 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(SceneRefs sc,
     p.d = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     p.coef = v3(1.0f, 1.0f, 1.0f); p.contrib = v3(0.0f, 0.0f, 0.0f); p.seg = 0;
     PhaseClock clk;
-    while (path_step<BVH, false>(p, sc, shade, mats, n_bounces, bsdf_model, clk)) {}
+    // "no depth limit" for the steps, so that false means the path ended; the depth is counted here, and the ray of
+    // a segment that ended the path is kept (the reference assigns `r` only when the path goes on, bsdf.h:165)
+    for (;;) {
+        const V3 o0 = p.o, d0 = p.d;
+        if (!path_step<BVH, false>(p, sc, shade, mats, 0x7fffffff, bsdf_model, clk)) { p.o = o0; p.d = d0; break; }
+        if (p.seg > n_bounces) break;
+    }
     rgb[3 * i] = p.contrib.x; rgb[3 * i + 1] = p.contrib.y; rgb[3 * i + 2] = p.contrib.z;
+    if (end_o) { end_o[3 * i] = p.o.x; end_o[3 * i + 1] = p.o.y; end_o[3 * i + 2] = p.o.z; }
+    if (end_d) { end_d[3 * i] = p.d.x; end_d[3 * i + 1] = p.d.y; end_d[3 * i + 2] = p.d.z; }
 }
 
 }  // namespace
@@ -1502,19 +1511,20 @@ int ptk_bsdf_batch_fast(int fn, const float* in, int n, float* out, hipStream_t 
 }
 
 int ptk_trace_paths_fast(const pt_scene* sc, const float* o, const float* d, const uint32_t* pixel,
-                         const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, int bsdf_model, float* rgb, hipStream_t s) {
+                         const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, int bsdf_model, float* rgb,
+                         float* end_o, float* end_d, hipStream_t s) {
     if (n <= 0) return 0;
     SceneRefs refs;
     if (sc->n_bnodes > 0) {
         refs.fdata = sc->d_fdata_top; refs.runs = sc->d_runs_top; refs.n_runs = sc->n_runs_top;
         refs.nodes = sc->d_bnodes; refs.bprims = sc->d_bprims; refs.n_nodes = sc->n_bnodes; refs.fat = nullptr;
         hipLaunchKernelGGL(trace_fast_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, s, refs,
-                           sc->d_fshade, sc->d_mats, o, d, pixel, sample, n, seed_hash, n_bounces, bsdf_model, rgb);
+                           sc->d_fshade, sc->d_mats, o, d, pixel, sample, n, seed_hash, n_bounces, bsdf_model, rgb, end_o, end_d);
     } else {
         refs.fdata = sc->d_fdata; refs.runs = sc->d_runs; refs.n_runs = sc->n_runs;
         refs.nodes = nullptr; refs.bprims = nullptr; refs.n_nodes = 0; refs.fat = nullptr;
         hipLaunchKernelGGL(trace_fast_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, s, refs,
-                           sc->d_fshade, sc->d_mats, o, d, pixel, sample, n, seed_hash, n_bounces, bsdf_model, rgb);
+                           sc->d_fshade, sc->d_mats, o, d, pixel, sample, n, seed_hash, n_bounces, bsdf_model, rgb, end_o, end_d);
     }
     PT_CHECK(hipGetLastError());
     return 0;

@@ -100,16 +100,27 @@ __global__ __launch_bounds__(256) void nearest_kernel(const DPrim* __restrict__ 
 __global__ __launch_bounds__(256) void trace_parity_kernel(const DPrim* __restrict__ prims, int n_prims, const DMat* __restrict__ mats,
                                                            const float* __restrict__ o, const float* __restrict__ d,
                                                            const uint32_t* __restrict__ pixel, const uint32_t* __restrict__ sample,
-                                                           int n, uint32_t seed_hash, int n_bounces, int bsdf_model, float* rgb) {
+                                                           int n, uint32_t seed_hash, int n_bounces, int bsdf_model, float* rgb,
+                                                           float* end_o, float* end_d) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Path p;
     p.key = rng_key(seed_hash, pixel[i], sample[i]);
     p.o = load3(o, i); p.d = load3(d, i);
     p.coef = v3(1.0f, 1.0f, 1.0f); p.contrib = v3(0.0f, 0.0f, 0.0f); p.seg = 0;
-    if (bsdf_model == PT_BSDF_CLASSES) { while (path_step_alt(p, prims, n_prims, mats, n_bounces)) {} }
-    else { while (path_step(p, prims, n_prims, mats, n_bounces)) {} }
+    // The steps are asked for "no depth limit", so that false means the path ended (miss, roulette); the depth is
+    // counted here.  The reference leaves in `r` the last ray it assigned (bsdf.h:165): a segment that ends the path
+    // assigns none, the last segment of a path that runs out of bounces does.
+    for (;;) {
+        const V3 o0 = p.o, d0 = p.d;
+        const bool alive = bsdf_model == PT_BSDF_CLASSES ? path_step_alt(p, prims, n_prims, mats, 0x7fffffff)
+                                                         : path_step(p, prims, n_prims, mats, 0x7fffffff);
+        if (!alive) { p.o = o0; p.d = d0; break; }
+        if (p.seg > n_bounces) break;
+    }
     store3(rgb, i, p.contrib);
+    if (end_o) store3(end_o, i, p.o);
+    if (end_d) store3(end_d, i, p.d);
 }
 
 __global__ void rng_kernel(uint32_t seed_hash, uint32_t pixel, uint32_t sample, int n_slots, uint32_t* bits, float* u) {
@@ -152,10 +163,11 @@ int ptk_nearest_batch(const pt_scene* sc, const float* o, const float* d, int n,
 }
 
 int ptk_trace_paths_parity(const pt_scene* sc, const float* o, const float* d, const uint32_t* pixel,
-                           const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, int bsdf_model, float* rgb, hipStream_t s) {
+                           const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, int bsdf_model, float* rgb,
+                           float* end_o, float* end_d, hipStream_t s) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(trace_parity_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sc->d_prims, sc->n_prims, sc->d_mats,
-                       o, d, pixel, sample, n, seed_hash, n_bounces, bsdf_model, rgb);
+                       o, d, pixel, sample, n, seed_hash, n_bounces, bsdf_model, rgb, end_o, end_d);
     PT_CHECK(hipGetLastError());
     return 0;
 }

@@ -3,6 +3,8 @@
 // n_intersections.  Shape::getIntersections here runs the gfx950 kernel through
 // the C ABI, so this binary needs a GPU.  The distance checks after each block
 // are this repository's additions (the reference asserts counts only).
+#include <chrono>
+
 #include "mini_gtest.h"
 #include "../../include/pt/api.h"
 
@@ -111,6 +113,82 @@ TEST(PathTest, NearestTraceRender) {
     for (int i = 0; i < 32; i++) { EXPECT_EQ(fb[i].x(), 2.0f); EXPECT_EQ(fb[i].z(), 4.0f); }
     checkHipErrors(hipFree(fb));
     delete scene[0];
+}
+
+// One-ray calls keep the uploaded scene and the staging buffers from call to call: 10 000 of them take well under a
+// second, a mutated shape or material is seen at once, and tracePath leaves in `r` what the reference leaves there.
+TEST(ApiTest, OneRayCallsAreCachedAndSeeMutations) {
+    Material grey; grey.albedo = vec3(0.5f, 0.5f, 0.5f);
+    Material light; light.emissive = vec3(1.0f, 1.0f, 1.0f);
+    Affine3f back = IDENTITY; back.translation() = vec3(0, 0, -5);
+    Affine3f ball = IDENTITY; ball.translation() = vec3(0, 0, -3);
+    Shape* scene[2] = {new Plane(light, back), new Sphere(grey, ball)};
+    ray r(vec3(0, 0, 0), vec3(0, 0, -1));
+    IntersectionPoint first = getNearestIntersection(r, scene, 2);      // uploads
+    EXPECT_EQ(first.distance, 2.5f);
+    const auto t0 = std::chrono::steady_clock::now();
+    int agree = 0;
+    for (int k = 0; k < 10000; k++) {
+        IntersectionPoint ip = getNearestIntersection(r, scene, 2);
+        agree += ip.intersects && ip.distance == 2.5f;
+    }
+    const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("10000 getNearestIntersection calls: %.3f s\n", seconds);
+    EXPECT_EQ(agree, 10000);
+    EXPECT_EQ(seconds < 1.0, true);
+    // a shape replaced in the array, and a material changed in place: both are seen by the next call
+    delete scene[1];
+    Affine3f nearer = IDENTITY; nearer.translation() = vec3(0, 0, -2);
+    scene[1] = new Sphere(grey, nearer);
+    EXPECT_EQ(getNearestIntersection(r, scene, 2).distance, 1.5f);
+    scene[1]->material.albedo = vec3(0.25f, 0.5f, 0.75f);
+    EXPECT_EQ(getNearestIntersection(r, scene, 2).material.albedo.x(), 0.25f);
+    // one-shape queries go through the same cache
+    RayPath rp;
+    for (int k = 0; k < 2000; k++) rp = scene[1]->getIntersections(r);
+    EXPECT_EQ(rp.n_intersections, 2);
+    EXPECT_EQ(rp.first.distance, 1.5f);
+    pt::release_cached();
+    EXPECT_EQ(getNearestIntersection(r, scene, 2).distance, 1.5f);     // and come back after a release
+    delete scene[0]; delete scene[1];
+}
+
+TEST(ApiTest, TracePathLeavesItsLastRayInR) {
+    Material light; light.emissive = vec3(2.0f, 3.0f, 4.0f);              // albedo 0: the roulette ends the path on the light
+    Material white; white.albedo = vec3(1.0f, 1.0f, 1.0f);               // albedo 1: the roulette never ends a path
+    Affine3f t = IDENTITY; t.translation() = vec3(0, 0, -3);
+    pt_rng s;
+    {   // the path ends on its first segment: r stays the ray that was passed (bsdf.h:161 breaks before :165)
+        Shape* scene[1] = {new Plane(light, t)};
+        ray r(vec3(0, 0, 0), vec3(0, 0, -1));
+        vec3 c = tracePath(scene, 1, r, &s);
+        EXPECT_EQ(c.y(), 3.0f);
+        EXPECT_EQ(r.origin().z(), 0.0f); EXPECT_EQ(r.direction().z(), -1.0f);
+        delete scene[0];
+    }
+    {   // the first segment bounces, the second misses: r is the bounced ray, which starts on the plane
+        Shape* scene[1] = {new Plane(white, t)};
+        ray r(vec3(0, 0, 0), vec3(0, 0, -1));
+        vec3 c = tracePath(scene, 1, r, &s);
+        EXPECT_EQ(c.x(), 0.0f);
+        EXPECT_EQ(r.origin().z(), -3.0f);
+        EXPECT_EQ(r.direction().z() > 0.0f, true);                       // into the half space in front of the plane
+        EXPECT_NEAR(r.direction().norm(), 1.0, 1e-6);
+        // no bounces allowed: the only segment runs out of depth after assigning the new ray (bsdf.h:165), as above
+        ray r0(vec3(0, 0, 0), vec3(0, 0, -1));
+        tracePath(scene, 1, r0, &s, 0);
+        EXPECT_EQ(r0.origin().z(), -3.0f);
+        delete scene[0];
+    }
+}
+
+TEST(ApiTest, UnusedAliasesOfVecMathExist) {                              // vec_math.h:15-17
+    vec4 v(1, 2, 3, 4);
+    matrix4 m = matrix4::Identity();
+    Q4 q = Q4::Identity();
+    EXPECT_EQ((m * v).w(), 4.0f);
+    EXPECT_EQ(v.dot(v), 30.0f);
+    EXPECT_EQ(q.w(), 1.0f);
 }
 
 int main() { return RUN_ALL_TESTS(); }

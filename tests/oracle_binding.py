@@ -175,6 +175,17 @@ class Scene:
         return rgb
 
 
+def trace_paths_end(scene, o, d, pixel, sample, seed=0, n_bounces=5, bsdf_model=0):
+    """tracePath with the ray it leaves in `r`: (rgb, end_o, end_d)."""
+    o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32)
+    pixel = np.ascontiguousarray(pixel, np.uint32); sample = np.ascontiguousarray(sample, np.uint32)
+    n = o.shape[0]
+    rgb, eo, ed = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    scene.L.oracle_trace_paths_end(C.c_void_p(scene.h), _fp(o), _fp(d), _fp(pixel), _fp(sample), C.c_int(n), C.c_uint(seed),
+                                   C.c_int(n_bounces), C.c_int(bsdf_model), _fp(rgb), _fp(eo), _fp(ed))
+    return rgb, eo, ed
+
+
 def raypath(prim, o, d, filter=True):
     """Shape::getIntersections (filter) / getRayPath (no filter, local ray) for one primitive."""
     o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32)

@@ -309,3 +309,41 @@ def test_alternative_bsdf_model(torch, pt, oracle):
     assert big.bvh_nodes > 0 and torch.equal(a, b)
     with pytest.raises(pt.PtError):
         sc.render(pt.make_config(8, 8, 1, bsdf_model=7))
+
+
+@pytest.mark.parametrize("bsdf_model", [0, 1])
+def test_trace_paths_end_ray(torch, pt, oracle, bsdf_model):
+    """pt_trace_paths_end: the ray tracePath leaves in its `ray& r` (bsdf.h:165, bsdf_alternative.h:215) — the ray of
+    the segment on which the path ended, or the ray after the last bounce — against the oracle, whose tracePath
+    mutates r as the reference's does."""
+    osc = oracle.Scene(*oracle.default_scene())
+    sc = pt.Scene(*pt.default_scene())
+    n = 8192
+    cfg = oracle.make_config(256, 256, 16)
+    rng = np.random.default_rng(3)
+    pi = rng.integers(0, 256, n).astype(np.int32); pj = rng.integers(0, 256, n).astype(np.int32)
+    smp = rng.integers(0, 16, n).astype(np.uint32)
+    o, d = oracle.camera_rays(cfg, pi, pj, smp)
+    px = (pj * 256 + pi).astype(np.uint32)
+    for depth in (0, 1, 5):
+        ref_rgb, ref_o, ref_d = oracle.trace_paths_end(osc, o, d, px, smp, n_bounces=depth, bsdf_model=bsdf_model)
+        args = [torch.from_numpy(x).cuda() for x in (o, d, px.astype(np.int32), smp.astype(np.int32))]
+        rgb, eo, ed = sc.trace_paths_end(*args, n_bounces=depth, math_mode=pt.PT_MATH_PARITY, bsdf_model=bsdf_model)
+        rgb, eo, ed = rgb.cpu().numpy(), eo.cpu().numpy(), ed.cpu().numpy()
+        same_path = np.abs(rgb - ref_rgb).max(axis=1) <= tol.PARITY["path_abs"]
+        assert same_path.mean() >= tol.PARITY["path_share"]
+        # where the path is the same path, its last ray is the same ray
+        # (to 1e-5; a diffuse direction whose normal and sphere point nearly cancel amplifies the one-ULP difference
+        # between the device's and the host's sinf/cosf, hence the share and the looser cap)
+        err = np.maximum(np.abs(eo - ref_o), np.abs(ed - ref_d)).max(axis=1)[same_path]
+        assert (err <= 1e-5).mean() >= 0.999 and err.max() <= 1e-3, (depth, float(err.max()))
+        moved = (ref_o != o).any(axis=1)
+        assert (depth == 0 and bsdf_model == 0 and moved.mean() > 0.3) or depth > 0 or bsdf_model == 1
+        # the radiance is what pt_trace_paths returns
+        fn_rgb = sc.trace_paths(*args, n_bounces=depth, math_mode=pt.PT_MATH_PARITY, bsdf_model=bsdf_model).cpu().numpy()
+        assert (fn_rgb == rgb).all()
+        # fast kernels: same call, end rays finite and unit length
+        frgb, feo, fed = sc.trace_paths_end(*args, n_bounces=depth, math_mode=pt.PT_MATH_FAST, bsdf_model=bsdf_model)
+        assert torch.isfinite(feo).all() and torch.isfinite(fed).all()
+        ln = fed.norm(dim=1)            # unit length, or the zero vector that refract() leaves on total reflection (bsdf_alternative.h model)
+        assert bool((((ln - 1).abs() < 1e-4) | (ln == 0)).all())
