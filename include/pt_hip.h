@@ -164,10 +164,12 @@ float pt_focal_length(int nx, int ny, float v_height, float fov_deg);
  * max_x*max_y*3 float framebuffer in device memory (or, with fb_compact, room
  * for the rendered rows); only the rendered rows are written.  The image is
  * bitwise the same however the rows are split over calls or GPUs.  Pixel sums
- * (totalLight, main.cu:61-67) are kept as 32.32 fixed point: a pixel's sum of
- * sample radiances must stay below 2^31 per channel, a sample's radiance is
- * resolved to 2^-32, and a NaN sample adds nothing where the reference would
- * turn the pixel NaN.  n_samples is at most 2^24. */
+ * (totalLight, main.cu:61-67) are kept as signed 32.32 fixed point: a sample's
+ * radiance is resolved to 2^-32 and counts up to +-2^30 / n_samples per channel
+ * (an infinite radiance included), so a sum never leaves the range; a NaN sample
+ * adds nothing where the reference would turn the pixel NaN.  A scene whose own
+ * lights exceed that cap (n_samples x largest emissive component > 2^30) is
+ * refused.  n_samples is at most 2^24. */
 int pt_render(const pt_scene* scene, const pt_config* cfg, float* d_fb, void* stream);
 
 /* Shape::getIntersections (filter != 0; shapes.h:60-75) or Shape::getRayPath

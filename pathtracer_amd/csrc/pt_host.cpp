@@ -532,6 +532,14 @@ int pt_scene_upload_opt(const pt_prim* prims, int n_prims, const pt_material* ma
     for (int k = 0; k < n_prims; k++) {
         if (prims[k].type < PT_PLANE || prims[k].type > PT_SPHERE) return PT_FAIL("pt_scene_upload: unknown shape type");
         if (prims[k].material < 0 || prims[k].material >= n_mats) return PT_FAIL("pt_scene_upload: material index out of range");
+        // A transform with a NaN or infinite entry, or one that cannot be inverted (shapes.h:37 inverts it), has no
+        // usable T^-1: every record built from it would be NaN or infinite.  Bounds may be infinite (an unbounded
+        // plane, shapes.h:111-112) but not NaN.
+        for (int j = 0; j < 12; j++) if (!std::isfinite(prims[k].transform[j])) return PT_FAIL("pt_scene_upload: a transform entry is not finite");
+        for (int j = 0; j < 4; j++) if (std::isnan(prims[k].bounds[j])) return PT_FAIL("pt_scene_upload: a plane bound is NaN");
+        const Aff inv = aff_inverse(aff_load(prims[k].transform));
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++)
+            if (!std::isfinite(inv.m[i][j])) return PT_FAIL("pt_scene_upload: a transform is singular (no finite inverse)");
     }
     PT_CHECK(hipSetDevice(device));
     std::vector<DPrim> dp(n_prims);
@@ -580,16 +588,19 @@ int pt_scene_upload_opt(const pt_prim* prims, int n_prims, const pt_material* ma
         }
     }
     std::vector<DMat> dm(n_mats);
+    float max_emissive = 0.0f;
     for (int i = 0; i < n_mats; i++) {
         std::memset(&dm[i], 0, sizeof(DMat));
         std::memcpy(&dm[i], &mats[i], sizeof(pt_material));
         const float* em = mats[i].emissive;
-        dm[i].emits = (fmaxf(em[0], fmaxf(em[1], em[2])) > 0.0f || fminf(em[0], fminf(em[1], em[2])) < 0.0f) ? 1 : 0;
+        // emissive.norm() > 0 (bsdf.h:90) as float arithmetic has it: false for a NaN component, false when the squares underflow
+        dm[i].emits = (em[0] * em[0] + (em[1] * em[1] + em[2] * em[2])) > 0.0f ? 1 : 0;
+        for (int c = 0; c < 3; c++) if (std::isfinite(em[c])) max_emissive = std::max(max_emissive, fabsf(em[c]));
     }
     pt_scene* sc = new (std::nothrow) pt_scene();
     if (!sc) return PT_FAIL("pt_scene_upload: out of host memory");
     std::memset(sc, 0, sizeof(*sc));
-    sc->device = device; sc->n_prims = n_prims; sc->n_mats = n_mats;
+    sc->device = device; sc->n_prims = n_prims; sc->n_mats = n_mats; sc->max_emissive = max_emissive;
     hipError_t e;
 #define UP(dst, vec, T)                                                                        \
     e = hipMalloc((void**)&sc->dst, vec.size() * sizeof(T));                                   \
@@ -668,6 +679,10 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     if (cfg->max_x <= 0 || cfg->max_y <= 0 || cfg->n_samples <= 0 || cfg->n_bounces < 0)
         return PT_FAIL("pt_render: bad image size, n_samples or n_bounces");
     if (cfg->n_samples > (1 << 24)) return PT_FAIL("pt_render: n_samples above 2^24");
+    // Pixel sums are 32.32 fixed point and a sample counts up to 2^30 / n_samples (ptw::to_fixed), so a sum cannot
+    // leave the range; a light whose own emission is beyond that cap would be dimmed silently, so it is refused.
+    if ((double)sc->max_emissive * (double)cfg->n_samples > 1073741824.0)
+        return PT_FAIL("pt_render: n_samples x the largest emissive component exceeds 2^30, the range of a pixel's sum");
     if ((uint64_t)cfg->max_x * (uint64_t)cfg->max_y > 0x7fffffffull) return PT_FAIL("pt_render: image above 2^31 pixels");
     if (cfg->row_begin < 0 || cfg->row_end > cfg->max_y || cfg->row_begin > cfg->row_end)
         return PT_FAIL("pt_render: row tile outside the image");
@@ -695,6 +710,7 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     a.du = du[0]; a.dv = dv[1];
     a.max_x = cfg->max_x; a.max_y = cfg->max_y;
     a.n_samples = cfg->n_samples; a.n_bounces = cfg->n_bounces; a.bsdf_model = cfg->bsdf_model;
+    a.sample_cap = 1073741824.0f / (float)cfg->n_samples;
     a.seed_hash = host_hash(cfg->seed + 0x9E3779B9u);
     const int row_step = cfg->row_step == 0 ? 1 : cfg->row_step;
     a.row_begin = cfg->row_begin; a.row_step = row_step;

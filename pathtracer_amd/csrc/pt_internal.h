@@ -147,6 +147,7 @@ struct pt_scene {
     float* d_fdata_top;
     FRun* d_runs_top;
     int n_runs_top;
+    float max_emissive;                    // largest finite |emissive component| of the materials
     int tune[PT_TUNE_COUNT];               // pt_scene_tune: 0 = the library's choice
     float* d_slot_box;                     // world-space box (lo.xyz, hi.xyz) of every record of `sorted`, in its order
     int n_slots;
@@ -160,6 +161,7 @@ struct RenderArgs {
     float du, dv;          // pixel_delta_u.x, pixel_delta_v.y
     int32_t max_x, max_y;
     int32_t n_samples, n_bounces;
+    float sample_cap;      // 2^30 / n_samples: what one sample's radiance counts as at most (pixel sums are 32.32 fixed point)
     int32_t bsdf_model;    // PT_BSDF_*
     uint32_t seed_hash;    // H(seed + 0x9E3779B9)
     int32_t row_begin, row_step, n_rows;   // rendered rows: row_begin + k*row_step, k in [0, n_rows)

@@ -80,7 +80,7 @@ void rotate(float m[12], float angle, float ax, float ay, float az) {   // Angle
 extern "C" {
 
 int pt_scene_parse(const char* text, pt_prim* prims, int cap_prims, pt_material* mats, int cap_mats, int* n_mats) {
-    if (!text || !prims || !mats || !n_mats) return -pt_set_error(-1, "pt_scene_parse: null argument", __FILE__, __LINE__);
+    if (!text || !prims || !mats || !n_mats) { pt_set_error(-1, "pt_scene_parse: null argument", __FILE__, __LINE__); return -1; }
     std::map<std::string, int> mat_index;
     int np = 0, nm = 0, line_no = 0;
     std::istringstream in(text);

@@ -436,7 +436,11 @@ PTD void walk_hierarchy(V3 o, V3 d, float dd, float idd, const BNode* __restrict
 // the (distance, scene index) rule the leaves apply.
 PTD void walk_fat(V3 o, V3 d, float dd, float idd, const BFat* __restrict__ fat, const BPrim* __restrict__ prims,
                   Best& b, int& cur, int& sp, uint32_t* stack, int budget) {
-    const V3 inv = v3(rcp(d.x), rcp(d.y), rcp(d.z));
+    // 1/d kept finite (+-1e30): with an infinite reciprocal, plane*inv - o*inv is inf - inf = NaN for every box on the
+    // origin's side of an axis the ray does not move along, v_min/v_max drop the NaN, and that axis never culls — the
+    // walk stays correct but an axis-parallel ray would descend most of the tree
+    const V3 inv = v3(__builtin_amdgcn_fmed3f(rcp(d.x), -1e30f, 1e30f), __builtin_amdgcn_fmed3f(rcp(d.y), -1e30f, 1e30f),
+                      __builtin_amdgcn_fmed3f(rcp(d.z), -1e30f, 1e30f));
     const V3 noi = v3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
     for (;;) {
         while (budget > 0) {
@@ -450,8 +454,8 @@ PTD void walk_fat(V3 o, V3 d, float dd, float idd, const BFat* __restrict__ fat,
             budget--;
             const float4* N = reinterpret_cast<const float4*>(fat + cur);
             const float4 A0 = N[0], A1 = N[1], B0 = N[2], B1 = N[3];
-            // slab tests of both boxes as plane*inv - o*inv; a NaN (0 * inf) drops out of v_min/v_max and leaves
-            // its axis unconstrained: conservative
+            // slab tests of both boxes as plane*inv - o*inv (inv is finite, see above; an origin exactly on a plane of
+            // an axis the ray does not move along gives 0 * 1e30 = 0: inside that slab)
             const float a0x = __builtin_fmaf(A0.x, inv.x, noi.x), a1x = __builtin_fmaf(A1.x, inv.x, noi.x);
             const float a0y = __builtin_fmaf(A0.y, inv.y, noi.y), a1y = __builtin_fmaf(A1.y, inv.y, noi.y);
             const float a0z = __builtin_fmaf(A0.z, inv.z, noi.z), a1z = __builtin_fmaf(A1.z, inv.z, noi.z);
@@ -700,7 +704,7 @@ PTD bool path_shade_alt(Path& p, const Best& b, const FShade* shade, const DMat*
     const DMat& M = mats[s.material];
     const V3 em = v3(M.emissive[0], M.emissive[1], M.emissive[2]);
     PHASE(clk, 2);
-    if ((max3(em.x, em.y, em.z) > 0.0f) || (min3(em.x, em.y, em.z) < 0.0f)) p.contrib = v3(__builtin_fmaf(em.x, p.coef.x, p.contrib.x), __builtin_fmaf(em.y, p.coef.y, p.contrib.y), __builtin_fmaf(em.z, p.coef.z, p.contrib.z));
+    if (M.emits != 0) p.contrib = v3(__builtin_fmaf(em.x, p.coef.x, p.contrib.x), __builtin_fmaf(em.y, p.coef.y, p.contrib.y), __builtin_fmaf(em.z, p.coef.z, p.contrib.z));
     const uint32_t slot = 2u + 6u * (uint32_t)p.seg;
     V3 ndir, w;
     if (M.bsdfType == 1) {
@@ -978,10 +982,10 @@ PTD void carve_wave_lds(uint32_t base, uint32_t P, uint32_t q_cap, BatchLds& L, 
     L.out_px = reinterpret_cast<uint32_t*>(ctx.pxt + 192);
 }
 
-PTD void add_light(const BatchLds& L, uint32_t px, V3 c) {
-    __hip_atomic_fetch_add(&L.acc[px * 3u], ptw::to_fixed(c.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    __hip_atomic_fetch_add(&L.acc[px * 3u + 1u], ptw::to_fixed(c.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    __hip_atomic_fetch_add(&L.acc[px * 3u + 2u], ptw::to_fixed(c.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+PTD void add_light(const BatchLds& L, uint32_t px, V3 c, float cap) {
+    __hip_atomic_fetch_add(&L.acc[px * 3u], ptw::to_fixed(c.x, cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __hip_atomic_fetch_add(&L.acc[px * 3u + 1u], ptw::to_fixed(c.y, cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __hip_atomic_fetch_add(&L.acc[px * 3u + 2u], ptw::to_fixed(c.z, cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
 // Which records of the kind-sorted table can a camera ray of this tile hit?  Bit s = record s (records are numbered
@@ -1096,7 +1100,7 @@ PTD uint32_t camera_batch(const RenderArgs& a, FastCtx& ctx, const BatchLds& L, 
     // again from its hit, with the hits that need shade_scatter anyway
     const bool as_hit = special || (hit && go_on && lit);
     const bool as_ray = hit && go_on && !as_hit;
-    if (hit && !as_hit && !go_on && lit) add_light(L, px, light);
+    if (hit && !as_hit && !go_on && lit) add_light(L, px, light, a.sample_cap);
     const unsigned long long park = __ballot(as_hit || as_ray);
     const uint32_t e = ptw::prefix_count(park);
     if (as_ray) {
@@ -1232,7 +1236,7 @@ PTD void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds&
                 const bool go_on = shade_scatter(path, s, M, ht, true, a.n_bounces, ctx.clk);
                 st = ACTIVE;
                 if (!go_on) {
-                    add_light(L, my_px, path.contrib);
+                    add_light(L, my_px, path.contrib, a.sample_cap);
                     st = FREE;
                 }
             }
@@ -1283,7 +1287,7 @@ PTD void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds&
         const bool go_on = shade_diffuse(path, s, M, hit, keep, a.n_bounces);
         PHASE(ctx.clk, 5);
         if (st == ACTIVE && !go_on) {
-            add_light(L, my_px, path.contrib);
+            add_light(L, my_px, path.contrib, a.sample_cap);
             st = FREE;
         }
         PHASE(ctx.clk, 6);

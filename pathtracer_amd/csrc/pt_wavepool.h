@@ -52,8 +52,11 @@ __device__ __forceinline__ PixelRef pixel_of(const RenderArgs& a, uint32_t lin) 
     return r;
 }
 
-// x >= 0 as 32.32 fixed point (floor(x) in the high word, the fraction in the low word).
-__device__ __forceinline__ unsigned long long to_fixed(float x) {
+// x as signed 32.32 fixed point (floor(x) in the high word, the fraction in the low word).  A NaN adds nothing;
+// anything beyond +-cap (an infinite radiance included) counts as +-cap, where cap = 2^30 / n_samples: whatever the
+// samples of a pixel are, their sum stays inside the 32 integer bits.
+__device__ __forceinline__ unsigned long long to_fixed(float x0, float cap) {
+    const float x = x0 == x0 ? __builtin_fminf(__builtin_fmaxf(x0, -cap), cap) : 0.0f;
     const float fl = __builtin_floorf(x);
     const unsigned lo = (unsigned)((x - fl) * 4294967296.0f);
     const int hi = (int)fl;
@@ -63,9 +66,9 @@ __device__ __forceinline__ float from_fixed(unsigned long long v) {
     return (float)(int)(v >> 32) + (float)(unsigned)v * 2.3283064365386963e-10f;
 }
 
-__device__ __forceinline__ void add_sample(WaveLds& l, uint32_t px, const float rgb[3]) {
+__device__ __forceinline__ void add_sample(WaveLds& l, uint32_t px, const float rgb[3], float cap) {
     for (int c = 0; c < 3; c++)
-        __hip_atomic_fetch_add(&l.acc[px * 3 + c], to_fixed(rgb[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(&l.acc[px * 3 + c], to_fixed(rgb[c], cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
 // p_color = totalLight / n_samples (main.cu:67); consecutive floats of consecutive pixels leave together.
@@ -159,7 +162,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, 
             if (active && !go_on) {
                 float rgb[3];
                 T::radiance(path, rgb);
-                add_sample(l, my_px, rgb);
+                add_sample(l, my_px, rgb, a.sample_cap);
                 active = false;
             }
         } else if (active) {
@@ -168,7 +171,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, 
             if (!go_on) {
                 float rgb[3];
                 T::radiance(path, rgb);
-                add_sample(l, my_px, rgb);
+                add_sample(l, my_px, rgb, a.sample_cap);
                 active = false;
             }
         }
@@ -227,7 +230,7 @@ __device__ __forceinline__ void render_tile_blocksync(const RenderArgs& a, uint3
             if (!go_on) {
                 float rgb[3];
                 T::radiance(path, rgb);
-                add_sample(l, my_px, rgb);
+                add_sample(l, my_px, rgb, a.sample_cap);
                 active = false;
                 T::idle(path);
             }

@@ -214,6 +214,8 @@ int main(int argc, char** argv) {
         if (rc != 0) { std::cerr << pt_last_error() << "\n"; return 99; }
     }
     const int tile_rows = pt_tile_rows(ny, n_tiles);
+    std::vector<float*> d_gathered((size_t)n_tiles, nullptr), d_full((size_t)n_tiles, nullptr);
+    std::vector<vec3*> d_tiles((size_t)n_tiles, nullptr);
     auto worker = [&](int k) {
         const int g = k % n_gpus;
         checkHipErrors(hipSetDevice(g));
@@ -225,6 +227,15 @@ int main(int argc, char** argv) {
         pt::DeviceScene dscene(scene.data(), n_objs, g);
         vec3* d_fb = nullptr;
         checkHipErrors(hipMalloc((void**)&d_fb, (size_t)tile_rows * nx * sizeof(vec3)));
+        /* The collective's buffers exist before anything is launched and are freed only after every thread has
+           joined: hipMalloc / hipFree synchronise the device, and doing that while another rank's RCCL kernel of the
+           same collective is in flight is how a process that drives several GPUs deadlocks. */
+        const size_t row_bytes = (size_t)nx * sizeof(vec3);
+        if (gather_rccl) {
+            checkHipErrors(hipMalloc((void**)&d_gathered[(size_t)k], (size_t)n_tiles * tile_rows * row_bytes));
+            checkHipErrors(hipMalloc((void**)&d_full[(size_t)k], (size_t)ny * row_bytes));
+        }
+        d_tiles[(size_t)k] = d_fb;
         hipEvent_t e0, e1;
         checkHipErrors(hipEventCreate(&e0)); checkHipErrors(hipEventCreate(&e1));
         checkHipErrors(hipEventRecord(e0, nullptr));
@@ -235,27 +246,28 @@ int main(int argc, char** argv) {
         float t = 0.0f;
         checkHipErrors(hipEventElapsedTime(&t, e0, e1));
         ms[k] = t;
-        const size_t row_bytes = (size_t)nx * sizeof(vec3);
         if (gather_rccl) {
-            float *d_gathered = nullptr, *d_full = nullptr;
-            checkHipErrors(hipMalloc((void**)&d_gathered, (size_t)n_tiles * tile_rows * row_bytes));
-            checkHipErrors(hipMalloc((void**)&d_full, (size_t)ny * row_bytes));
-            if (pt_gather_framebuffer(comms[(size_t)k], reinterpret_cast<const float*>(d_fb), d_gathered, d_full, ny, nx, nullptr) != 0) {
+            if (pt_gather_framebuffer(comms[(size_t)k], reinterpret_cast<const float*>(d_fb), d_gathered[(size_t)k], d_full[(size_t)k], ny, nx, nullptr) != 0) {
                 std::cerr << pt_last_error() << "\n";
                 std::exit(99);
             }
             checkHipErrors(hipDeviceSynchronize());
-            if (k == 0) checkHipErrors(hipMemcpy(fb.data(), d_full, (size_t)ny * row_bytes, hipMemcpyDeviceToHost));
-            checkHipErrors(hipFree(d_gathered)); checkHipErrors(hipFree(d_full));
+            if (k == 0) checkHipErrors(hipMemcpy(fb.data(), d_full[0], (size_t)ny * row_bytes, hipMemcpyDeviceToHost));
         } else {
             checkHipErrors(hipMemcpy2D(fb.data() + (size_t)k * nx, row_bytes * n_tiles, d_fb, row_bytes, row_bytes, my_rows, hipMemcpyDeviceToHost));
         }
-        checkHipErrors(hipFree(d_fb));
     };
     std::vector<std::thread> threads;
     for (int k = 1; k < n_tiles; k++) threads.emplace_back(worker, k);
     worker(0);
     for (auto& t : threads) t.join();
+    for (int k = 0; k < n_tiles; k++) {
+        if (!d_tiles[(size_t)k]) continue;
+        checkHipErrors(hipSetDevice(k % n_gpus));
+        checkHipErrors(hipFree(d_tiles[(size_t)k]));
+        if (d_gathered[(size_t)k]) checkHipErrors(hipFree(d_gathered[(size_t)k]));
+        if (d_full[(size_t)k]) checkHipErrors(hipFree(d_full[(size_t)k]));
+    }
     for (pt_comm* c : comms) pt_comm_free(c);
 
     if (stats) {

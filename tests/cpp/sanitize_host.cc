@@ -148,6 +148,13 @@ static void run_parser(const char* scene_path) {
     int n = 0;
     parse(text, 64, 64, &n);
     check(n == 11, "default.scene has 11 shapes");
+    {   // a null argument is an error (-1), never a primitive count
+        pt_prim one; pt_material m; int nm = 0;
+        check(pt_scene_parse(nullptr, &one, 1, &m, 1, &nm) == -1, "null text is refused");
+        check(pt_scene_parse(text.c_str(), nullptr, 1, &m, 1, &nm) == -1, "null primitive table is refused");
+        check(pt_scene_parse(text.c_str(), &one, 1, nullptr, 1, &nm) == -1, "null material table is refused");
+        check(pt_scene_parse(text.c_str(), &one, 1, &m, 1, nullptr) == -1, "null material count is refused");
+    }
     parse(text, 3, 64, &n);   check(n == -1, "too few shape slots is an error");
     parse(text, 64, 2, &n);   check(n == -1, "too few material slots is an error");
     parse(text, 0, 0, &n);
