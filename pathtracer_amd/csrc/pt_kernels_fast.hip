@@ -983,9 +983,17 @@ PTD void carve_wave_lds(uint32_t base, uint32_t P, uint32_t q_cap, BatchLds& L, 
 }
 
 PTD void add_light(const BatchLds& L, uint32_t px, V3 c, float cap) {
-    __hip_atomic_fetch_add(&L.acc[px * 3u], ptw::to_fixed(c.x, cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    __hip_atomic_fetch_add(&L.acc[px * 3u + 1u], ptw::to_fixed(c.y, cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    __hip_atomic_fetch_add(&L.acc[px * 3u + 2u], ptw::to_fixed(c.z, cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    // one test for "some channel is a NaN or beyond the cap" (the compare is false for a NaN); the clamp itself
+    // (ptw::to_fixed) then only runs for such samples
+    if (!(max3(__builtin_fabsf(c.x), __builtin_fabsf(c.y), __builtin_fabsf(c.z)) <= cap) || c.x != c.x || c.y != c.y || c.z != c.z) {
+        __hip_atomic_fetch_add(&L.acc[px * 3u], ptw::to_fixed(c.x, cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(&L.acc[px * 3u + 1u], ptw::to_fixed(c.y, cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(&L.acc[px * 3u + 2u], ptw::to_fixed(c.z, cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        return;
+    }
+    __hip_atomic_fetch_add(&L.acc[px * 3u], ptw::to_fixed_in_range(c.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __hip_atomic_fetch_add(&L.acc[px * 3u + 1u], ptw::to_fixed_in_range(c.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __hip_atomic_fetch_add(&L.acc[px * 3u + 2u], ptw::to_fixed_in_range(c.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
 // Which records of the kind-sorted table can a camera ray of this tile hit?  Bit s = record s (records are numbered

@@ -55,12 +55,14 @@ __device__ __forceinline__ PixelRef pixel_of(const RenderArgs& a, uint32_t lin) 
 // x as signed 32.32 fixed point (floor(x) in the high word, the fraction in the low word).  A NaN adds nothing;
 // anything beyond +-cap (an infinite radiance included) counts as +-cap, where cap = 2^30 / n_samples: whatever the
 // samples of a pixel are, their sum stays inside the 32 integer bits.
-__device__ __forceinline__ unsigned long long to_fixed(float x0, float cap) {
-    const float x = x0 == x0 ? __builtin_fminf(__builtin_fmaxf(x0, -cap), cap) : 0.0f;
+__device__ __forceinline__ unsigned long long to_fixed_in_range(float x) {      // |x| <= 2^30, not a NaN
     const float fl = __builtin_floorf(x);
     const unsigned lo = (unsigned)((x - fl) * 4294967296.0f);
     const int hi = (int)fl;
     return ((unsigned long long)(unsigned)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long to_fixed(float x0, float cap) {
+    return to_fixed_in_range(x0 == x0 ? __builtin_fminf(__builtin_fmaxf(x0, -cap), cap) : 0.0f);
 }
 __device__ __forceinline__ float from_fixed(unsigned long long v) {
     return (float)(int)(v >> 32) + (float)(unsigned)v * 2.3283064365386963e-10f;
