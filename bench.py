@@ -46,16 +46,33 @@ def flops_per_sample():
         return float(json.load(f)[FLOPS_KEY]["flops_per_sample"])
 
 
-def measured_traffic_bytes(kernel):
-    """HBM bytes per launch of the full-frame render kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01/pmc_render_fast_i.json: WRITE_SIZE and FETCH_SIZE in KB, separate passes; FETCH_SIZE doubled
-    as the gfx950 counter reports half the bytes of wide reads).  None when no profile of that kernel is stored."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_render_fast_i.json")
-    if kernel != "render_fast_kernel" or not os.path.exists(path):
+STORED_COUNTERS = os.path.join("profiles", "r02", "pmc_config2.json")
+
+
+def stored_counters(kernel, kernel_ms):
+    """What the committed rocprofv3 --pmc passes of this kernel on this frame say (STORED_COUNTERS; five separate
+    passes, per-launch averages), priced with this run's kernel time: HBM bytes per launch (WRITE_SIZE + 2 x
+    FETCH_SIZE, in KB; the gfx950 fetch counter reports half the bytes of wide reads), the FP32 rate the hardware
+    executed (issue slots of FMA x 2 + MUL + ADD + TRANS, x 64 lanes), the vector issue rate beside the
+    microbenchmark's rate for the same mix, lane utilisation and occupancy.  The counters are NOT collected by this
+    run: they go stale when the kernel changes, which is why the source file and its kernel name are in the line.
+    None when no pass of that kernel is stored."""
+    path = os.path.join(ROOT, STORED_COUNTERS)
+    if not os.path.exists(path):
         return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary
     with open(path) as f:
-        d = json.load(f)
-    return (d["write"]["per_dispatch"]["WRITE_SIZE"] + 2.0 * d["fetch"]["per_dispatch"]["FETCH_SIZE"]) * 1024.0
+        pmc = json.load(f)
+    if kernel not in pmc.get("profiled_kernel", ""):
+        return None
+    d = pmc_summary.derive(pmc, kernel_ms)
+    return {"source": STORED_COUNTERS + " (stored counter passes, not collected by this run)",
+            "traffic": d["hbm_bytes"], "executed_tflops": d["executed_tflops"], "executed_frac": d["executed_frac"],
+            "executed_tflops_active_lanes": d["executed_tflops_active_lanes"],
+            "valu_issue_rate": d["valu_issue_rate"], "valu_issue_ceiling": d["valu_issue_ceiling"],
+            "valu_issue_unit": "wave-instructions / ns / SIMD", "lane_util": d["lane_util"], "occupancy": d["occupancy"],
+            "valu_wave_instructions": d["valu_wave_instructions"]}
 
 
 def cpu_baseline(gpu_image):
@@ -78,7 +95,8 @@ def cpu_baseline(gpu_image):
                       % ("every row" if CPU_ROW_STEP == 1 else "rows j %% %d == 0" % CPU_ROW_STEP, len(rows), samples / 1e6, dt)}
     img = gpu_image.cpu().numpy()[rows].astype(np.float64)
     ref = ref[rows].astype(np.float64)
-    parity = {"rows": int(len(rows)),
+    parity = {"pinned_by": "the CPU restatement only: the reference's own fixtures pin hit counts, nothing else (parity unpinned beyond hit counts)",
+              "rows": int(len(rows)),
               "rmse_rel": float(np.sqrt(((img - ref) ** 2).mean(axis=(0, 1))).max() / ref.mean()),
               "bad_pixel_frac": float((np.abs(img - ref).max(axis=2) > 0.05).mean()),
               "mean_rel": float((np.abs(img.mean(axis=(0, 1)) - ref.mean(axis=(0, 1))) / ref.mean(axis=(0, 1))).max())}
@@ -136,6 +154,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--math", choices=["fast", "parity", "scalar", "lds"], default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--general-kinds", action="store_true",
+                    help="upload the scene with the general record kinds only (what a scene with rotated shapes gets); not the headline")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: gather each frame before rendering the next")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="development aid on one GPU: render rank 0's share of an N-GPU run with the N-GPU pipeline, no collectives")
@@ -165,7 +185,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     prims, n, mats, nm = pt.default_scene()
-    scene = pt.Scene(prims, n, mats, nm, device=local_rank)
+    scene = pt.Scene(prims, n, mats, nm, device=local_rank, general_kinds=pt.PT_GENERAL_ALL if args.general_kinds else 0)
     math_mode = {"fast": pt.PT_MATH_FAST, "parity": pt.PT_MATH_PARITY, "scalar": pt.PT_MATH_FAST_SCALAR, "lds": pt.PT_MATH_FAST_LDS}[args.math]
     # rank r renders rows r, r+N, ... into a compact tile; all-gather + strided copy rebuild the image
     part = emulate or world              # ranks the frame is split over
@@ -277,6 +297,9 @@ def main():
         # its neighbour's; the launch rate is then what prices the kernel: algorithmic flops per launch / time per step.
         launch_ms = elapsed / args.steps * 1e3 if overlap else kernel_ms
         achieved = fps * tile_samples / (launch_ms * 1e-3) / 1e12
+        kernel = {"fast": "render_fast_batched_kernel", "scalar": "render_fast_kernel", "lds": "render_fast_tiled_kernel",
+                  "parity": "render_parity_kernel"}[args.math]
+        counters = stored_counters(kernel, kernel_ms) if world == 1 and not emulate and not args.general_kinds else None
         out = {
             "metric": "Msamples/sec at 1080p 64spp",
             "value": total_samples * args.steps / elapsed / 1e6,
@@ -285,16 +308,20 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "reference default scene (main.cu:73-195), 1920x1080, 64 spp, depth 5, seed 0",
+            "config": {"workload": "reference default scene (main.cu:73-195), 1920x1080, 64 spp, depth 5, seed 0"
+                                   + (" [general record kinds only: not the headline]" if args.general_kinds else ""),
                        "math_mode": args.math, "partition": "rows r, r+%d, ... per rank, all-gather + strided copy%s%s" % (part, ", gather of frame k overlapped with render of frame k+1, frames on alternating streams" if overlap else "", " [EMULATED rank 0 of %d on one GPU, no collectives]" % emulate if emulate else ""),
                        "flops_per_sample": fps},
-            "roofline": {"bound": "valu_fp32", "kernel": {"fast": "render_fast_kernel", "scalar": "render_fast_kernel", "lds": "render_fast_tiled_kernel", "parity": "render_parity_kernel"}[args.math],
+            "roofline": {"bound": "valu_fp32", "kernel": kernel,
                          "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VALU_PEAK_TFLOPS,
-                         "traffic": measured_traffic_bytes("render_fast_kernel" if args.math == "fast" else args.math) if world == 1 and not emulate else None,
+                         "achieved_is": "algorithmic flops (event table of the reference's arithmetic) / kernel time; executed_* below is what the hardware issued",
+                         "traffic": counters["traffic"] if counters else None,
                          "kernel_ms": kernel_ms, "kernel_msamples_per_s": tile_samples / launch_ms / 1e3,
                          "launches_overlap": bool(overlap)},
         }
+        if counters:
+            out["roofline"].update({k: v for k, v in counters.items() if k != "traffic"})
         if part > 1:
             # the rate above is a pipeline rate: frames_in_flight frames render and gather concurrently; the time of
             # one frame rendered and gathered on its own is given beside it

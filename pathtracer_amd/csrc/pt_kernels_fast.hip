@@ -983,6 +983,8 @@ PTD void carve_wave_lds(uint32_t base, uint32_t P, uint32_t q_cap, BatchLds& L, 
 }
 
 PTD void add_light(const BatchLds& L, uint32_t px, V3 c, float cap) {
+    // most paths end without having met a light: a zero adds nothing to a fixed-point sum (nor does a negative zero)
+    if (c.x == 0.0f && c.y == 0.0f && c.z == 0.0f) return;
     // one test for "some channel is a NaN or beyond the cap" (the compare is false for a NaN); the clamp itself
     // (ptw::to_fixed) then only runs for such samples
     if (!(max3(__builtin_fabsf(c.x), __builtin_fabsf(c.y), __builtin_fabsf(c.z)) <= cap) || c.x != c.x || c.y != c.y || c.z != c.z) {

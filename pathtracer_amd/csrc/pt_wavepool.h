@@ -69,6 +69,8 @@ __device__ __forceinline__ float from_fixed(unsigned long long v) {
 }
 
 __device__ __forceinline__ void add_sample(WaveLds& l, uint32_t px, const float rgb[3], float cap) {
+    // most paths end without having met a light: a zero adds nothing to a fixed-point sum (nor does a negative zero)
+    if (rgb[0] == 0.0f && rgb[1] == 0.0f && rgb[2] == 0.0f) return;
     for (int c = 0; c < 3; c++)
         __hip_atomic_fetch_add(&l.acc[px * 3 + c], to_fixed(rgb[c], cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
