@@ -186,6 +186,12 @@ int pt_raypath_batch(const pt_scene* scene, int prim, const float* d_o, const fl
 int pt_nearest_batch(const pt_scene* scene, const float* d_o, const float* d_d, int n_rays,
                      int32_t* d_prim, float* d_t, float* d_pos, float* d_nrm, int32_t* d_inside, void* stream);
 
+/* The same through the PT_MATH_FAST kernels' search (kind-sorted records, and the hierarchy when the scene has
+ * one): what pt_render(PT_MATH_FAST) finds per segment, reachable on its own so that its distances, positions and
+ * normals can be compared with pt_nearest_batch's.  math_mode: PT_MATH_PARITY (= pt_nearest_batch) or PT_MATH_FAST. */
+int pt_nearest_batch_mode(const pt_scene* scene, const float* d_o, const float* d_d, int n_rays, int math_mode,
+                          int32_t* d_prim, float* d_t, float* d_pos, float* d_nrm, int32_t* d_inside, void* stream);
+
 /* tracePath (bsdf.h:73-168) for n_rays explicit rays; ray i draws from the
  * stream (seed, d_pixel[i], d_sample[i]) starting at slot 2.  d_rgb: [n_rays][3]. */
 int pt_trace_paths(const pt_scene* scene, const float* d_o, const float* d_d, const uint32_t* d_pixel,

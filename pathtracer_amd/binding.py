@@ -78,6 +78,7 @@ def _load():
     L.pt_render.argtypes = [vp, C.POINTER(pt_config), vp, vp]
     L.pt_raypath_batch.argtypes = [vp, i32, vp, vp, i32, i32] + [vp] * 9 + [vp]
     L.pt_nearest_batch.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.pt_nearest_batch_mode.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.pt_trace_paths.argtypes = [vp, vp, vp, vp, vp, i32, u32, i32, i32, vp, vp]
     L.pt_trace_paths_alt.argtypes = [vp, vp, vp, vp, vp, i32, u32, i32, i32, vp, vp]
     L.pt_trace_paths_end.argtypes = [vp, vp, vp, vp, vp, i32, u32, i32, i32, i32, vp, vp, vp, vp]
@@ -108,7 +109,7 @@ lib = _load()
 
 EXPORTS = [
     "pt_scene_upload", "pt_scene_upload_opt", "pt_scene_tune", "pt_scene_free", "pt_scene_device", "pt_scene_bvh_nodes", "pt_default_scene", "pt_glass_grid_scene",
-    "pt_synthetic_scene", "pt_focal_length", "pt_render", "pt_raypath_batch", "pt_nearest_batch",
+    "pt_synthetic_scene", "pt_focal_length", "pt_render", "pt_raypath_batch", "pt_nearest_batch", "pt_nearest_batch_mode",
     "pt_trace_paths", "pt_trace_paths_alt", "pt_trace_paths_end", "pt_rng_draws", "pt_bsdf_batch", "pt_bsdf_arity", "pt_ppm_p3", "pt_last_error", "pt_version",
     "pt_scene_parse", "pt_ppm_p6", "pt_pfm",
     "pt_tile_rows", "pt_comm_unique_id", "pt_comm_init_rank", "pt_comm_init_all", "pt_comm_free", "pt_comm_rank",
@@ -299,7 +300,9 @@ class Scene:
                                         _ptr(res["hit2"]), _ptr(res["t2"]), _ptr(res["pos2"]), _ptr(res["nrm2"]), _stream()))
         return res
 
-    def nearest(self, o, d):
+    def nearest(self, o, d, math_mode=PT_MATH_PARITY):
+        """getNearestIntersection for rays o, d ([n][3] device tensors); math_mode PT_MATH_FAST runs the search of the
+        fast render kernels (pt_nearest_batch_mode)."""
         torch = _torch()
         n = o.shape[0]
         dev = self._dev()
@@ -308,8 +311,12 @@ class Scene:
                    nrm=torch.zeros((n, 3), dtype=torch.float32, device=dev),
                    inside=torch.zeros(n, dtype=torch.int32, device=dev))
         with torch.cuda.device(self.device):
-            _check(lib.pt_nearest_batch(self.h, _ptr(o), _ptr(d), n, _ptr(res["prim"]), _ptr(res["t"]),
-                                        _ptr(res["pos"]), _ptr(res["nrm"]), _ptr(res["inside"]), _stream()))
+            if math_mode == PT_MATH_PARITY:
+                _check(lib.pt_nearest_batch(self.h, _ptr(o), _ptr(d), n, _ptr(res["prim"]), _ptr(res["t"]),
+                                            _ptr(res["pos"]), _ptr(res["nrm"]), _ptr(res["inside"]), _stream()))
+            else:
+                _check(lib.pt_nearest_batch_mode(self.h, _ptr(o), _ptr(d), n, math_mode, _ptr(res["prim"]), _ptr(res["t"]),
+                                                 _ptr(res["pos"]), _ptr(res["nrm"]), _ptr(res["inside"]), _stream()))
         return res
 
     def trace_paths_end(self, o, d, pixel, sample, seed=0, n_bounces=5, math_mode=PT_MATH_PARITY, bsdf_model=PT_BSDF_REFERENCE):

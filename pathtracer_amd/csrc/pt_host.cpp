@@ -794,6 +794,15 @@ int pt_nearest_batch(const pt_scene* sc, const float* d_o, const float* d_d, int
     return ptk_nearest_batch(sc, d_o, d_d, n_rays, d_prim, d_t, d_pos, d_nrm, d_inside, (hipStream_t)stream);
 }
 
+int pt_nearest_batch_mode(const pt_scene* sc, const float* d_o, const float* d_d, int n_rays, int math_mode,
+                          int32_t* d_prim, float* d_t, float* d_pos, float* d_nrm, int32_t* d_inside, void* stream) {
+    if (!sc || !d_o || !d_d || n_rays < 0) return PT_FAIL("pt_nearest_batch_mode: bad arguments");
+    if (math_mode != PT_MATH_PARITY && math_mode != PT_MATH_FAST) return PT_FAIL("pt_nearest_batch_mode: unknown math_mode");
+    PT_CHECK(hipSetDevice(sc->device));
+    if (math_mode == PT_MATH_PARITY) return ptk_nearest_batch(sc, d_o, d_d, n_rays, d_prim, d_t, d_pos, d_nrm, d_inside, (hipStream_t)stream);
+    return ptk_nearest_batch_fast(sc, d_o, d_d, n_rays, d_prim, d_t, d_pos, d_nrm, d_inside, (hipStream_t)stream);
+}
+
 static int trace_paths(const char* who, const pt_scene* sc, const float* d_o, const float* d_d, const uint32_t* d_pixel,
                        const uint32_t* d_sample, int n_rays, uint32_t seed, int n_bounces, int math_mode, int bsdf_model,
                        float* d_rgb, float* d_end_o, float* d_end_d, void* stream) {

@@ -211,6 +211,8 @@ int ptk_trace_paths_fast(const pt_scene* sc, const float* o, const float* d, con
                          const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, int bsdf_model, float* rgb,
                          float* end_o, float* end_d, hipStream_t s);
 int ptk_bsdf_batch_parity(int fn, const float* in, int n, float* out, hipStream_t s);
+int ptk_nearest_batch_fast(const pt_scene* sc, const float* o, const float* d, int n, int32_t* prim, float* t,
+                           float* pos, float* nrm, int32_t* inside, hipStream_t s);
 int ptk_bsdf_batch_fast(int fn, const float* in, int n, float* out, hipStream_t s);
 int ptk_rng_draws(uint32_t seed_hash, uint32_t pixel, uint32_t sample, int n_slots, uint32_t* bits, float* u, hipStream_t s);
 

@@ -1437,6 +1437,30 @@ __global__ __launch_bounds__(256) void trace_fast_kernel(SceneRefs sc,
     if (end_d) { end_d[3 * i] = p.d.x; end_d[3 * i + 1] = p.d.y; end_d[3 * i + 2] = p.d.z; }
 }
 
+// getNearestIntersection as the render kernels run it: the kind-sorted loops (all records, or the ones outside the
+// hierarchy followed by the skip-link walk), then the winner's surface.
+template <bool BVH>
+__global__ __launch_bounds__(256) void nearest_fast_kernel(SceneRefs sc, const FShade* __restrict__ shade,
+                                                           const float* __restrict__ o, const float* __restrict__ d, int n,
+                                                           int32_t* prim, float* t, float* pos, float* nrm, int32_t* inside) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3 ro = v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    Best b = best_none();
+    const float dd = dot(rd, rd), idd = rcp(dd);
+    scan_sorted(ro, rd, dd, idd, sc.sorted, b);
+    if (BVH) { int visits = 0; walk_hierarchy(ro, rd, dd, idd, sc.nodes, sc.n_nodes, sc.bprims, b, visits, 0x7fffffff); }
+    const bool hit = b.id >= 0;
+    if (prim) prim[i] = hit ? (b.id >> 3) : -1;
+    Surf s;
+    s.pos = v3(0.0f, 0.0f, 0.0f); s.nrm = s.pos; s.inside = false;
+    if (hit) s = surface(b, ro, rd, shade);
+    if (t) t[i] = hit ? b.t : 0.0f;
+    if (pos) { pos[3 * i] = s.pos.x; pos[3 * i + 1] = s.pos.y; pos[3 * i + 2] = s.pos.z; }
+    if (nrm) { nrm[3 * i] = s.nrm.x; nrm[3 * i + 1] = s.nrm.y; nrm[3 * i + 2] = s.nrm.z; }
+    if (inside) inside[i] = hit && s.inside ? 1 : 0;
+}
+
 }  // namespace
 
 #ifdef PT_PHASE_PROF
@@ -1520,6 +1544,22 @@ __global__ __launch_bounds__(256) void bsdf_fast_kernel(int fn, const float* __r
 int ptk_bsdf_batch_fast(int fn, const float* in, int n, float* out, hipStream_t s) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(bsdf_fast_kernel, dim3((n + 255) / 256), dim3(256), 0, s, fn, in, n, out);
+    PT_CHECK(hipGetLastError());
+    return 0;
+}
+
+int ptk_nearest_batch_fast(const pt_scene* sc, const float* o, const float* d, int n, int32_t* prim, float* t,
+                           float* pos, float* nrm, int32_t* inside, hipStream_t s) {
+    if (n <= 0) return 0;
+    SceneRefs refs;
+    refs.fdata = nullptr; refs.runs = nullptr; refs.n_runs = 0; refs.fat = nullptr;
+    if (sc->n_bnodes > 0) {
+        refs.sorted = sc->sorted_top; refs.nodes = sc->d_bnodes; refs.bprims = sc->d_bprims; refs.n_nodes = sc->n_bnodes;
+        hipLaunchKernelGGL(nearest_fast_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, s, refs, sc->d_fshade, o, d, n, prim, t, pos, nrm, inside);
+    } else {
+        refs.sorted = sc->sorted; refs.nodes = nullptr; refs.bprims = nullptr; refs.n_nodes = 0;
+        hipLaunchKernelGGL(nearest_fast_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, s, refs, sc->d_fshade, o, d, n, prim, t, pos, nrm, inside);
+    }
     PT_CHECK(hipGetLastError());
     return 0;
 }
