@@ -219,7 +219,13 @@ int bake_fast(const pt_prim& p, const Aff& fwd, const Aff& inv, int general, flo
                                          fwd.m[0][1] == 0.0f && fwd.m[0][2] == 0.0f && fwd.m[1][0] == 0.0f && fwd.m[1][2] == 0.0f &&
                                          fwd.m[2][0] == 0.0f && fwd.m[2][1] == 0.0f &&
                                          inv.m[0][0] == inv.m[1][1] && inv.m[0][0] == inv.m[2][2];
-            if (scaled_identity && (general & PT_GENERAL_SPHERES) == 0) {
+            // A sphere whose centre lies many diameters from the origin (|q| = |centre| / s large) has its discriminant
+            // cancel to a few bits: what the test returns there is mostly rounding, and the short form above rounds
+            // differently from the reference's d_l = T^-1 d, a = d_l.d_l (measured on 10 000 spheres of diameter 0.01-0.03,
+            // |q| up to 500: mean radiance +0.27 % against the parity-order kernel with the short form, +0.05 % with the
+            // general one).  Such spheres keep the general record, which follows the reference's operations.
+            const float q_max = fmaxf(fabsf(inv.m[0][3]), fmaxf(fabsf(inv.m[1][3]), fabsf(inv.m[2][3])));
+            if (scaled_identity && q_max <= 32.0f && (general & PT_GENERAL_SPHERES) == 0) {
                 *ftype = FP_SPHERE_WS;
                 const float k = inv.m[0][0];
                 rec[0] = k; rec[1] = inv.m[0][3]; rec[2] = inv.m[1][3]; rec[3] = inv.m[2][3];

@@ -34,21 +34,25 @@ def _rms_by_group_size(d, par_mean):
     return rms, {s: v / par_mean.mean() for s, v in rms.items()}
 
 
-@pytest.mark.parametrize("name,depth,general", [("default", 5, 0), ("glass grid", 31, 0), ("glass grid, general sphere records", 31, 4)])
+@pytest.mark.parametrize("name,depth,general", [("default", 5, 0), ("glass grid", 31, 0), ("glass grid, general sphere records", 31, 4),
+                                                ("10 000 small shapes", 5, 0)])
 def test_fast_minus_parity_shrinks_with_the_number_of_seeds(pt, name, depth, general):
     from pathtracer_amd import binding as b
     assert general in (0, b.PT_GENERAL_SPHERES)
-    scene = pt.Scene(*(pt.default_scene() if name == "default" else pt.glass_grid_scene(5)), general_kinds=general)
+    small = name == "10 000 small shapes"
+    scene = pt.Scene(*(pt.default_scene() if name == "default" else (pt.synthetic_scene(5000, 4989, 12345) if small else pt.glass_grid_scene(5))),
+                     general_kinds=general)
     d, par_mean = _seed_averaged_difference(pt, scene, depth)
     rms, rel = _rms_by_group_size(d, par_mean)
     print("%s: RMS of the seed-averaged difference / mean radiance: %s" % (name, {s: "%.4f" % v for s, v in rel.items()}))
     assert rms[1] > 0.0                                                  # the two kernels do differ somewhere
-    assert rel[1] <= 3.0 * tol.fast_image_rmse(SPP)                      # one seed: branch-flip noise (small frame, depth 31: x3)
+    # one seed: branch-flip noise (small frame, depth 31: x3; shapes smaller than a pixel, whose every sample is a near miss: x12)
+    assert rel[1] <= (12.0 if small else 3.0) * tol.fast_image_rmse(SPP)
     # noise law: each doubling of the seeds takes sqrt(2) off; a bias floor would stop the fall
     assert rms[32] <= 1.5 * rms[1] / np.sqrt(32.0), rel
     bias = np.abs(d.mean(axis=(0, 1, 2))) / par_mean                     # per channel, all seeds and pixels
     print("%s: per-channel mean of fast - parity over %d seeds, relative: %s" % (name, SEEDS, bias))
-    assert (bias <= tol.FAST["bias_mean_rel"]).all(), bias
+    assert (bias <= tol.FAST["bias_mean_rel_small_shapes" if small else "bias_mean_rel"]).all(), bias
 
 
 # History of the glass-grid case: uniformly scaled spheres used to be tested in world space (|o - centre|^2 - r^2).
@@ -58,3 +62,9 @@ def test_fast_minus_parity_shrinks_with_the_number_of_seeds(pt, name, depth, gen
 # The world-space test lost fewer: +0.3 % in the mean, up to +40 % in pixels on the rims of the spheres nearest the light,
 # an RMS floor of 3.4 % that no number of seeds removed.  The test above found it; the record kind now evaluates
 # o_l = k*o + q as the reference does, and the floor is gone (mean 0.03 %, within the noise of 32 seeds).
+#
+# The 10 000-shape case: spheres of diameter 0.01-0.03 up to 5 units away have their discriminant cancel to a few bits in
+# float, in the reference's frame as in any other, so a hit's position is off the surface by far more than the 1e-5
+# filter and what the next segment sees depends on how the test rounds.  The short sphere record gave +0.27 % in the mean
+# there; spheres that far out (|centre| / scale > 32) now keep the general record, whose operations are the reference's:
+# +0.05 % (red, blue), +0.2 % (green), with a noise of 0.09 % at this sample count.

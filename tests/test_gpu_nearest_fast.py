@@ -56,7 +56,8 @@ def check(name, pt, oracle, scene, n_rays, seed, **scene_kw):
     assert (~(same | explained)).mean() <= tol.FAST["nearest_grazing"], (name, int((~(same | explained)).sum()))
     assert same.mean() >= 1.0 - tol.FAST["nearest_prim_mismatch"], (name, 1.0 - same.mean())
     # same primitive, other root: a ray that starts on a sphere or cube and sees, or does not see, the surface it leaves
-    flip = hit & (np.abs(tg - tr) > 1e-2 * np.maximum(np.minimum(tg, tr), 1e-3))
+    with np.errstate(invalid="ignore"):          # inf - inf where both miss
+        flip = hit & (np.abs(tg - tr) > 1e-2 * np.maximum(np.minimum(tg, tr), 1e-3))
     assert flip.mean() <= tol.FAST["nearest_prim_mismatch"], (name, flip.mean())
     hit &= ~flip
     # distances.  For a camera ray (origin 0) the error is that of the test's arithmetic: in ULPs of t.  For a ray that
