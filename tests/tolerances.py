@@ -1,5 +1,5 @@
-"""The parity bounds of this repository in one place: every GPU test, __graft_entry__.smoke() and DESIGN.md's
-tolerance table read them from here.  All image quantities are relative to the mean radiance of the reference image;
+"""The parity bounds of this repository in one place: every GPU test and __graft_entry__.smoke() read them
+from here.  All image quantities are relative to the mean radiance of the reference image;
 "bad pixel" = a pixel whose largest channel difference exceeds BAD_PIXEL_ABS.
 
 The reference pins hit counts only (tests/shape_test.cc), so everything below is kernel-versus-oracle (the CPU
@@ -53,7 +53,7 @@ FAST_NEAREST = {
 }
 
 # Scenes whose paths are long or whose hits are decided by near-ties get their own, looser, image bounds (same
-# quantities; measured values in DESIGN.md's tolerance table).
+# quantities).
 GLASS_DEPTH_31 = {       # 5x5 glass spheres, 32 segments, 160x90@16: almost every path crosses several refractions
     "parity_image_rmse": 0.02, "parity_bad_pixel_frac": 0.002,
     "fast_image_rmse": 0.2, "fast_bad_pixel_frac": 0.02, "fast_mean_rel": 0.02,
