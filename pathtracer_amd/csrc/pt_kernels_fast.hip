@@ -338,9 +338,17 @@ template <int N> PTD void axis_planes(KFloatP R, int n, V3 o, V3 d, V3 inv, Best
 // The loop of getNearestIntersection over the kind-sorted records: one typed loop per kind, offsets and counts from
 // the kernel arguments (no run table to fetch, no switch).  Every index is wave-uniform, so records arrive by scalar
 // loads; a record's scene index << 3 sits right behind it.  Planes go two per trip: one wait covers both records.
+//
+// KM: the kinds the caller knows the table can hold (bit FP_*); a loop whose kind is not in it is not compiled, and
+// its offset and count are never read.  KM_SHORT is the table of a scene whose planes and cubes lie along the world
+// axes and whose spheres are uniformly scaled.
+constexpr int KM_ALL = (1 << FP_KINDS) - 1;
+constexpr int KM_SHORT = (1 << FP_SPHERE_WS) | (1 << FP_PLANE_X) | (1 << FP_PLANE_Y) | (1 << FP_PLANE_Z) | (1 << FP_CUBE_AA);
+template <int KM = KM_ALL>
 PTD void scan_sorted(V3 o, V3 d, float dd, float idd, const FSorted& S, Best& b) {
     const KFloatP base = as_constant(S.data);
-    if (S.count[FP_PLANE_X] + S.count[FP_PLANE_Y] + S.count[FP_PLANE_Z] + S.count[FP_CUBE_AA] > 0) {
+    constexpr int AXIS = (1 << FP_PLANE_X) | (1 << FP_PLANE_Y) | (1 << FP_PLANE_Z) | (1 << FP_CUBE_AA);
+    if ((KM & AXIS) != 0 && (KM == KM_SHORT || S.count[FP_PLANE_X] + S.count[FP_PLANE_Y] + S.count[FP_PLANE_Z] + S.count[FP_CUBE_AA] > 0)) {
         const V3 inv = v3(rcp(d.x), rcp(d.y), rcp(d.z));
         axis_planes<0>(base + S.off[FP_PLANE_X], S.count[FP_PLANE_X], o, d, inv, b);
         axis_planes<1>(base + S.off[FP_PLANE_Y], S.count[FP_PLANE_Y], o, d, inv, b);
@@ -348,7 +356,7 @@ PTD void scan_sorted(V3 o, V3 d, float dd, float idd, const FSorted& S, Best& b)
         KFloatP R = base + S.off[FP_CUBE_AA];
         for (int i = S.count[FP_CUBE_AA]; i > 0; i--, R += 8) test_cube_box(R, o, inv, __float_as_int(R[6]), b);
     }
-    {
+    if (KM & (1 << FP_PLANE)) {
         KFloatP R = base + S.off[FP_PLANE];
         int i = 0;
         const int n = S.count[FP_PLANE];
@@ -358,23 +366,23 @@ PTD void scan_sorted(V3 o, V3 d, float dd, float idd, const FSorted& S, Best& b)
         }
         if (i < n) test_plane(R, o, d, __float_as_int(R[12]), b);
     }
-    {
+    if (KM & (1 << FP_PLANE_GEN)) {
         KFloatP R = base + S.off[FP_PLANE_GEN];
         for (int i = S.count[FP_PLANE_GEN]; i > 0; i--, R += 20) test_plane_gen(R, o, d, __float_as_int(R[16]), b);
     }
-    {
+    if (KM & (1 << FP_SPHERE_WS)) {
         KFloatP R = base + S.off[FP_SPHERE_WS];
         for (int i = S.count[FP_SPHERE_WS]; i > 0; i--, R += 8) test_sphere_ws(R, o, d, dd, idd, __float_as_int(R[6]), b);
     }
-    {
+    if (KM & (1 << FP_SPHERE)) {
         KFloatP R = base + S.off[FP_SPHERE];
         for (int i = S.count[FP_SPHERE]; i > 0; i--, R += 16) test_sphere(R, o, d, __float_as_int(R[12]), b);
     }
-    {
+    if (KM & (1 << FP_CUBE)) {
         KFloatP R = base + S.off[FP_CUBE];
         for (int i = S.count[FP_CUBE]; i > 0; i--, R += 16) test_cube(R, o, d, __float_as_int(R[12]), b);
     }
-    {
+    if (KM & (1 << FP_CYLINDER)) {
         KFloatP R = base + S.off[FP_CYLINDER];
         for (int i = S.count[FP_CYLINDER]; i > 0; i--, R += 16) test_cylinder(R, o, d, __float_as_int(R[12]), b);
     }
@@ -1040,12 +1048,13 @@ PTD unsigned long long tile_candidates(const RenderArgs& a, uint32_t lin_base, u
 // scan_sorted over the records whose bit is set in `mask` (bit s = record s, numbered through the kinds in FP_*
 // order, which is the order of this function).  Same tests, same (distance, index) rule: the result is scan_sorted's
 // whenever no record that the ray hits is masked out.
+template <int KM = KM_ALL>
 PTD void scan_sorted_masked(V3 o, V3 d, float dd, float idd, const FSorted& S, unsigned long long mask, Best& b) {
     const KFloatP base = as_constant(S.data);
     const V3 inv = v3(rcp(d.x), rcp(d.y), rcp(d.z));
     int first = 0;
 #define PT_KIND_LOOP(KIND, STRIDE, ID_AT, CALL)                                                              \
-    {                                                                                                        \
+    if (KM & (1 << KIND)) {                                                                                  \
         const int cnt = S.count[KIND];                                                                       \
         unsigned long long m = cnt > 0 ? (mask >> first) & (cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull)) : 0ull; \
         first += cnt;                                                                                        \
@@ -1071,7 +1080,7 @@ PTD void scan_sorted_masked(V3 o, V3 d, float dd, float idd, const FSorted& S, u
 // The first segment of pool items made .. made + 63, one per lane: camera ray (main.cu:62-64), nearest hit among the
 // tile's candidate records, surface, emissive term and — for a hit that shade_diffuse covers — new direction and
 // roulette.  What goes on is parked in L.stash, packed from entry 0; returns the number of entries.
-template <bool SORTED>
+template <bool SORTED, int KM>
 PTD uint32_t camera_batch(const RenderArgs& a, FastCtx& ctx, const BatchLds& L, const SceneRefs& sc, unsigned long long cand,
                           uint32_t made, uint32_t total, uint32_t lin_base, uint32_t npx, unsigned lane) {
     using T = FastTracer<0, SORTED>;
@@ -1087,8 +1096,8 @@ PTD uint32_t camera_batch(const RenderArgs& a, FastCtx& ctx, const BatchLds& L, 
     {
         const float dd = dot(d, d), idd = rcp(dd);
         if (SORTED) {
-            if (a.slot_box != nullptr && a.n_slots <= 64) scan_sorted_masked(o, d, dd, idd, sc.sorted, cand, b0);
-            else scan_sorted(o, d, dd, idd, sc.sorted, b0);
+            if (a.slot_box != nullptr && a.n_slots <= 64) scan_sorted_masked<KM>(o, d, dd, idd, sc.sorted, cand, b0);
+            else scan_sorted<KM>(o, d, dd, idd, sc.sorted, b0);
         } else {
             scan_runs(o, d, dd, idd, as_constant(sc.fdata), as_constant(sc.runs), 0, sc.n_runs, b0);
         }
@@ -1124,7 +1133,7 @@ PTD uint32_t camera_batch(const RenderArgs& a, FastCtx& ctx, const BatchLds& L, 
     return (uint32_t)__popcll(park);
 }
 
-template <bool LDS_TABLES, bool SORTED>
+template <bool LDS_TABLES, bool SORTED, int KM>
 PTD void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds& L, FastCtx& ctx) {
     using T = FastTracer<0, SORTED>;
     enum { FREE = 0, ACTIVE = 1, GLASS = 2 };
@@ -1199,7 +1208,7 @@ PTD void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds&
             for (int pass = 0; pass < 2 && need != 0u; pass++) {
                 if (parked == 0u) {
                     if (made >= total) break;
-                    parked = camera_batch<SORTED>(a, ctx, L, sc, cand, made, total, lin_base, npx, lane);
+                    parked = camera_batch<SORTED, KM>(a, ctx, L, sc, cand, made, total, lin_base, npx, lane);
 #ifdef PT_BATCH_ONLY
                     parked = 0;
 #endif
@@ -1260,7 +1269,7 @@ PTD void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds&
         Best b0 = best_none();
         {
             const float dd = dot(path.d, path.d), idd = rcp(dd);
-            if (SORTED) scan_sorted(path.o, path.d, dd, idd, sc.sorted, b0);
+            if (SORTED) scan_sorted<KM>(path.o, path.d, dd, idd, sc.sorted, b0);
             else scan_runs(path.o, path.d, dd, idd, as_constant(sc.fdata), as_constant(sc.runs), 0, sc.n_runs, b0);
         }
         PHASE(ctx.clk, 1);
@@ -1316,7 +1325,7 @@ PTD void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds&
     }
 }
 
-template <bool LDS_TABLES, bool SORTED>
+template <bool LDS_TABLES, bool SORTED, int KM>
 __global__ __launch_bounds__(ptw::BLOCK) void render_fast_batched_kernel(RenderArgs a, uint32_t n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     const uint32_t P = 1u << a.tile_log2;
@@ -1345,7 +1354,7 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_batched_kernel(RenderA
     carve_wave_lds(wave_lds, P, (uint32_t)a.q_cap, L, ctx);
     ctx.wstack = nullptr;
     ctx.clk.start();
-    render_tile_batched<LDS_TABLES, SORTED>(a, tile, L, ctx);
+    render_tile_batched<LDS_TABLES, SORTED, KM>(a, tile, L, ctx);
     ctx.clk.flush(threadIdx.x & 63);
 }
 
@@ -1504,8 +1513,14 @@ int ptk_render_fast(const RenderArgs& a, int variant, hipStream_t s) {
             // queue by q_cap, the tables by the scene.
             const size_t table_bytes = tables ? (size_t)a.n_prims * sizeof(FShade) + (size_t)a.n_mats * sizeof(DMat) : 0;
             const size_t lds = batched_wave_bytes(1u << a.tile_log2, (uint32_t)a.q_cap) * ptw::WAVES_PER_BLOCK + table_bytes;
-            if (tables) hipLaunchKernelGGL((render_fast_batched_kernel<true, true>), dim3(blocks), dim3(ptw::BLOCK), lds, s, a, n_tiles);
-            else hipLaunchKernelGGL((render_fast_batched_kernel<false, true>), dim3(blocks), dim3(ptw::BLOCK), lds, s, a, n_tiles);
+            // a table that holds short kinds only gets the loop without the others' code
+            int kinds = 0;
+            for (int k = 0; k < FP_KINDS; k++) if (a.sorted.count[k] > 0) kinds |= 1 << k;
+            const bool short_only = (kinds & ~KM_SHORT) == 0;
+            if (tables && short_only) hipLaunchKernelGGL((render_fast_batched_kernel<true, true, KM_SHORT>), dim3(blocks), dim3(ptw::BLOCK), lds, s, a, n_tiles);
+            else if (tables) hipLaunchKernelGGL((render_fast_batched_kernel<true, true, KM_ALL>), dim3(blocks), dim3(ptw::BLOCK), lds, s, a, n_tiles);
+            else if (short_only) hipLaunchKernelGGL((render_fast_batched_kernel<false, true, KM_SHORT>), dim3(blocks), dim3(ptw::BLOCK), lds, s, a, n_tiles);
+            else hipLaunchKernelGGL((render_fast_batched_kernel<false, true, KM_ALL>), dim3(blocks), dim3(ptw::BLOCK), lds, s, a, n_tiles);
         } else if (sorted) {
             if (tables) hipLaunchKernelGGL((render_fast_kernel<true, 0, true>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
             else hipLaunchKernelGGL((render_fast_kernel<false, 0, true>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
