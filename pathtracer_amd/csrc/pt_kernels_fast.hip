@@ -343,6 +343,8 @@ template <int N> PTD void axis_planes(KFloatP R, int n, V3 o, V3 d, V3 inv, Best
 // its offset and count are never read.  KM_SHORT is the table of a scene whose planes and cubes lie along the world
 // axes and whose spheres are uniformly scaled.
 constexpr int KM_ALL = (1 << FP_KINDS) - 1;
+constexpr int KM_PLANES = (1 << FP_PLANE) | (1 << FP_PLANE_GEN) | (1 << FP_PLANE_X) | (1 << FP_PLANE_Y) | (1 << FP_PLANE_Z);   // what stays outside a hierarchy
+constexpr int KM_GENERAL = (1 << FP_PLANE) | (1 << FP_CUBE) | (1 << FP_CYLINDER) | (1 << FP_SPHERE) | (1 << FP_PLANE_GEN);   // no short kind
 constexpr int KM_SHORT = (1 << FP_SPHERE_WS) | (1 << FP_PLANE_X) | (1 << FP_PLANE_Y) | (1 << FP_PLANE_Z) | (1 << FP_CUBE_AA);
 template <int KM = KM_ALL>
 PTD void scan_sorted(V3 o, V3 d, float dd, float idd, const FSorted& S, Best& b) {
@@ -350,11 +352,13 @@ PTD void scan_sorted(V3 o, V3 d, float dd, float idd, const FSorted& S, Best& b)
     constexpr int AXIS = (1 << FP_PLANE_X) | (1 << FP_PLANE_Y) | (1 << FP_PLANE_Z) | (1 << FP_CUBE_AA);
     if ((KM & AXIS) != 0 && (KM == KM_SHORT || S.count[FP_PLANE_X] + S.count[FP_PLANE_Y] + S.count[FP_PLANE_Z] + S.count[FP_CUBE_AA] > 0)) {
         const V3 inv = v3(rcp(d.x), rcp(d.y), rcp(d.z));
-        axis_planes<0>(base + S.off[FP_PLANE_X], S.count[FP_PLANE_X], o, d, inv, b);
-        axis_planes<1>(base + S.off[FP_PLANE_Y], S.count[FP_PLANE_Y], o, d, inv, b);
-        axis_planes<2>(base + S.off[FP_PLANE_Z], S.count[FP_PLANE_Z], o, d, inv, b);
-        KFloatP R = base + S.off[FP_CUBE_AA];
-        for (int i = S.count[FP_CUBE_AA]; i > 0; i--, R += 8) test_cube_box(R, o, inv, __float_as_int(R[6]), b);
+        if (KM & (1 << FP_PLANE_X)) axis_planes<0>(base + S.off[FP_PLANE_X], S.count[FP_PLANE_X], o, d, inv, b);
+        if (KM & (1 << FP_PLANE_Y)) axis_planes<1>(base + S.off[FP_PLANE_Y], S.count[FP_PLANE_Y], o, d, inv, b);
+        if (KM & (1 << FP_PLANE_Z)) axis_planes<2>(base + S.off[FP_PLANE_Z], S.count[FP_PLANE_Z], o, d, inv, b);
+        if (KM & (1 << FP_CUBE_AA)) {
+            KFloatP R = base + S.off[FP_CUBE_AA];
+            for (int i = S.count[FP_CUBE_AA]; i > 0; i--, R += 8) test_cube_box(R, o, inv, __float_as_int(R[6]), b);
+        }
     }
     if (KM & (1 << FP_PLANE)) {
         KFloatP R = base + S.off[FP_PLANE];
@@ -809,7 +813,7 @@ PTD bool path_step_walk(WalkPath& p, const SceneRefs& sc, const FShade* shade, c
     const float dd = dot(p.d, p.d), idd = rcp(dd);
     if (p.node < 0) {
         p.best = best_none();
-        scan_sorted(p.o, p.d, dd, idd, sc.sorted, p.best);
+        scan_sorted<KM_PLANES>(p.o, p.d, dd, idd, sc.sorted, p.best);      // only planes stay outside the hierarchy
         p.node = 0;
         p.sp = 0;
     }
@@ -1457,7 +1461,8 @@ __global__ __launch_bounds__(256) void nearest_fast_kernel(SceneRefs sc, const F
     const V3 ro = v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     Best b = best_none();
     const float dd = dot(rd, rd), idd = rcp(dd);
-    scan_sorted(ro, rd, dd, idd, sc.sorted, b);
+    if (BVH) scan_sorted<KM_PLANES>(ro, rd, dd, idd, sc.sorted, b);
+    else scan_sorted(ro, rd, dd, idd, sc.sorted, b);
     if (BVH) { int visits = 0; walk_hierarchy(ro, rd, dd, idd, sc.nodes, sc.n_nodes, sc.bprims, b, visits, 0x7fffffff); }
     const bool hit = b.id >= 0;
     if (prim) prim[i] = hit ? (b.id >> 3) : -1;
@@ -1516,11 +1521,11 @@ int ptk_render_fast(const RenderArgs& a, int variant, hipStream_t s) {
             // a table that holds short kinds only gets the loop without the others' code
             int kinds = 0;
             for (int k = 0; k < FP_KINDS; k++) if (a.sorted.count[k] > 0) kinds |= 1 << k;
-            const bool short_only = (kinds & ~KM_SHORT) == 0;
-            if (tables && short_only) hipLaunchKernelGGL((render_fast_batched_kernel<true, true, KM_SHORT>), dim3(blocks), dim3(ptw::BLOCK), lds, s, a, n_tiles);
-            else if (tables) hipLaunchKernelGGL((render_fast_batched_kernel<true, true, KM_ALL>), dim3(blocks), dim3(ptw::BLOCK), lds, s, a, n_tiles);
-            else if (short_only) hipLaunchKernelGGL((render_fast_batched_kernel<false, true, KM_SHORT>), dim3(blocks), dim3(ptw::BLOCK), lds, s, a, n_tiles);
-            else hipLaunchKernelGGL((render_fast_batched_kernel<false, true, KM_ALL>), dim3(blocks), dim3(ptw::BLOCK), lds, s, a, n_tiles);
+            const bool short_only = (kinds & ~KM_SHORT) == 0, general_only = (kinds & ~KM_GENERAL) == 0;
+#define PT_LAUNCH_BATCHED(T, KM) hipLaunchKernelGGL((render_fast_batched_kernel<T, true, KM>), dim3(blocks), dim3(ptw::BLOCK), lds, s, a, n_tiles)
+            if (tables) { if (short_only) PT_LAUNCH_BATCHED(true, KM_SHORT); else if (general_only) PT_LAUNCH_BATCHED(true, KM_GENERAL); else PT_LAUNCH_BATCHED(true, KM_ALL); }
+            else { if (short_only) PT_LAUNCH_BATCHED(false, KM_SHORT); else if (general_only) PT_LAUNCH_BATCHED(false, KM_GENERAL); else PT_LAUNCH_BATCHED(false, KM_ALL); }
+#undef PT_LAUNCH_BATCHED
         } else if (sorted) {
             if (tables) hipLaunchKernelGGL((render_fast_kernel<true, 0, true>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
             else hipLaunchKernelGGL((render_fast_kernel<false, 0, true>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
