@@ -344,6 +344,7 @@ int pack_runs(const std::vector<Baked>& baked, const std::vector<int>& ids, std:
 void pack_sorted(const std::vector<Baked>& baked, const std::vector<int>& ids, std::vector<float>& data, FSorted& hdr,
                  std::vector<float>* boxes = nullptr) {
     std::memset(&hdr, 0, sizeof(hdr));
+    data.assign(32, 0.0f);      // head of the buffer: a copy of the offsets and counts (filled in below)
     for (int kind = 0; kind < FP_KINDS; kind++) {
         data.resize((data.size() + 15) / 16 * 16, 0.0f);
         hdr.off[kind] = (int32_t)data.size();
@@ -365,6 +366,9 @@ void pack_sorted(const std::vector<Baked>& baked, const std::vector<int>& ids, s
         }
     }
     data.resize(data.size() + 32, 0.0f);
+    static_assert(2 * FP_KINDS <= 32, "the header has 32 words");
+    std::memcpy(&data[0], hdr.off, sizeof(hdr.off));
+    std::memcpy(&data[FP_KINDS], hdr.count, sizeof(hdr.count));
 }
 
 // Median-split hierarchy over ids[lo, hi), appended to `nodes` in depth-first order.  Boxes are padded so that

@@ -346,9 +346,29 @@ constexpr int KM_ALL = (1 << FP_KINDS) - 1;
 constexpr int KM_PLANES = (1 << FP_PLANE) | (1 << FP_PLANE_GEN) | (1 << FP_PLANE_X) | (1 << FP_PLANE_Y) | (1 << FP_PLANE_Z);   // what stays outside a hierarchy
 constexpr int KM_GENERAL = (1 << FP_PLANE) | (1 << FP_CUBE) | (1 << FP_CYLINDER) | (1 << FP_SPHERE) | (1 << FP_PLANE_GEN);   // no short kind
 constexpr int KM_SHORT = (1 << FP_SPHERE_WS) | (1 << FP_PLANE_X) | (1 << FP_PLANE_Y) | (1 << FP_PLANE_Z) | (1 << FP_CUBE_AA);
+// The offsets and counts of the kinds.  From the kernel arguments they are loop invariants that the compiler keeps in
+// scalar registers for the whole kernel (twenty of them, plus a hoisted "count > 0" mask each): with every kind
+// compiled in, that costs 80 spilled scalars per loop iteration.  LAZY reads them from the copy at the head of the
+// record buffer instead, behind a pointer the compiler cannot see through, so they live only while a scan runs.
+#ifndef PT_LAZY_HEADER
+#define PT_LAZY_HEADER(KM) ((KM) == KM_ALL)
+#endif
+template <int KM>
+PTD void sorted_header(const FSorted& S, KFloatP base, int (&off)[FP_KINDS], int (&cnt)[FP_KINDS]) {
+    if (PT_LAZY_HEADER(KM)) {
+        KFloatP h = base;
+        asm volatile("" : "+s"(h));
+        for (int k = 0; k < FP_KINDS; k++) { off[k] = __float_as_int(h[k]); cnt[k] = __float_as_int(h[FP_KINDS + k]); }
+    } else {
+        for (int k = 0; k < FP_KINDS; k++) { off[k] = S.off[k]; cnt[k] = S.count[k]; }
+    }
+}
+
 template <int KM = KM_ALL>
-PTD void scan_sorted(V3 o, V3 d, float dd, float idd, const FSorted& S, Best& b) {
-    const KFloatP base = as_constant(S.data);
+PTD void scan_sorted(V3 o, V3 d, float dd, float idd, const FSorted& S0, Best& b) {
+    const KFloatP base = as_constant(S0.data);
+    struct { int off[FP_KINDS], count[FP_KINDS]; } S;
+    sorted_header<KM>(S0, base, S.off, S.count);
     constexpr int AXIS = (1 << FP_PLANE_X) | (1 << FP_PLANE_Y) | (1 << FP_PLANE_Z) | (1 << FP_CUBE_AA);
     if ((KM & AXIS) != 0 && (KM == KM_SHORT || S.count[FP_PLANE_X] + S.count[FP_PLANE_Y] + S.count[FP_PLANE_Z] + S.count[FP_CUBE_AA] > 0)) {
         const V3 inv = v3(rcp(d.x), rcp(d.y), rcp(d.z));
@@ -1053,8 +1073,10 @@ PTD unsigned long long tile_candidates(const RenderArgs& a, uint32_t lin_base, u
 // order, which is the order of this function).  Same tests, same (distance, index) rule: the result is scan_sorted's
 // whenever no record that the ray hits is masked out.
 template <int KM = KM_ALL>
-PTD void scan_sorted_masked(V3 o, V3 d, float dd, float idd, const FSorted& S, unsigned long long mask, Best& b) {
-    const KFloatP base = as_constant(S.data);
+PTD void scan_sorted_masked(V3 o, V3 d, float dd, float idd, const FSorted& S0, unsigned long long mask, Best& b) {
+    const KFloatP base = as_constant(S0.data);
+    struct { int off[FP_KINDS], count[FP_KINDS]; } S;
+    sorted_header<KM>(S0, base, S.off, S.count);
     const V3 inv = v3(rcp(d.x), rcp(d.y), rcp(d.z));
     int first = 0;
 #define PT_KIND_LOOP(KIND, STRIDE, ID_AT, CALL)                                                              \
