@@ -230,8 +230,11 @@ int pt_bsdf_batch(int device, int fn, int math_mode, const float* d_in, int n, f
 /* Floats per element going in and coming out of `fn` (0 on success). */
 int pt_bsdf_arity(int fn, int* n_in, int* n_out);
 
-/* Raw draws of the counter RNG: bits and (0,1] uniforms of slots [0,n_slots) of
- * stream (seed, pixel, sample), computed on the device. */
+/* Draws of the counter RNG for slots [0,n_slots) of stream (seed, pixel, sample), computed on the device: the hash
+ * bits of each slot, and the uniform the kernels use there.  Slots 0,1 are the pixel jitter; segment s uses slots
+ * 2+6s+{0 mode, 1,2 diffuse u1,u2, 3,4 roughness u1,u2, 5 roulette}.  A draw that decides a branch (mode, roulette)
+ * takes all 32 bits of its slot: bits * 2^-32 + 2^-33, in (0,1].  The two coordinates of a point (jitter; u1,u2) share
+ * the bits of the pair's first slot, 16 bits each: half * 2^-16 + 2^-17, in (0,1). */
 int pt_rng_draws(int device, uint32_t seed, uint32_t pixel, uint32_t sample, int n_slots,
                  uint32_t* d_bits, float* d_uniforms, void* stream);
 

@@ -311,7 +311,7 @@ void oracle_rng(unsigned seed, unsigned pixel, unsigned sample, int n_slots, uns
     pt_rng s = rng_init(seed, pixel, sample);
     for (int k = 0; k < n_slots; k++) {
         bits[k] = rng_bits(s.key, (uint32_t)k);
-        uniforms[k] = rng_to_uniform(bits[k]);
+        uniforms[k] = rng_slot_uniform(s.key, (uint32_t)k);
     }
 }
 

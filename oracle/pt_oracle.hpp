@@ -512,9 +512,15 @@ class Sphere : public Shape {
 //   K_px      = H(pixel_index ^ H(seed + 0x9E3779B9))
 //   K_smp     = H(K_px + 0x9E3779B9 * (sample + 1))
 //   bits(k)   = H(K_smp ^ (0x85EBCA6B * (k + 1)))        k = draw slot
-//   uniform   = (float)bits * 2^-32 + 2^-33   in float arithmetic  -> (0, 1]
 // Slot map: 0,1 = pixel jitter x,y; segment s: 2+6s+{0 mode, 1,2 diffuse u1,u2,
 // 3,4 refraction-roughness u1,u2, 5 Russian roulette}.
+// A draw that decides a branch (mode, roulette) uses all 32 bits of its slot:
+//   uniform   = (float)bits * 2^-32 + 2^-33   in float arithmetic  -> (0, 1]
+// The two coordinates of a point (jitter x,y; u1,u2 of a direction) share the
+// bits of the FIRST slot of their pair, 16 bits each, cell centres:
+//   u(first)     = (bits(first) >> 16)     * 2^-16 + 2^-17
+//   u(first + 1) = (bits(first) & 0xffff)  * 2^-16 + 2^-17         -> (0, 1)
+// (65 536 levels per coordinate; bits(first + 1) is never used).
 // ----------------------------------------------------------------------------
 inline uint32_t rng_hash(uint32_t x) {
     x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
@@ -533,7 +539,15 @@ inline pt_rng rng_init(uint32_t seed, uint32_t pixel_index, uint32_t sample) {
 }
 inline uint32_t rng_bits(uint32_t key, uint32_t slot) { return rng_hash(key ^ (0x85EBCA6Bu * (slot + 1u))); }
 inline float rng_to_uniform(uint32_t bits) { return (float)bits * 2.3283064365386963e-10f + 1.1641532182693481e-10f; }
-inline float rng_uniform(pt_rng* s) { return rng_to_uniform(rng_bits(s->key, s->slot++)); }
+inline float rng_half_to_uniform(uint32_t h16) { return (float)h16 * 1.52587890625e-05f + 7.62939453125e-06f; }
+// The uniform of draw slot k under the slot map above.
+inline float rng_slot_uniform(uint32_t key, uint32_t k) {
+    uint32_t j = k < 2u ? k + 1u : (k - 2u) % 6u;          // jitter behaves like the pair (1, 2) of a segment
+    if (j == 1u || j == 3u) return rng_half_to_uniform(rng_bits(key, k) >> 16);
+    if (j == 2u || j == 4u) return rng_half_to_uniform(rng_bits(key, k - 1u) & 0xffffu);
+    return rng_to_uniform(rng_bits(key, k));
+}
+inline float rng_uniform(pt_rng* s) { return rng_slot_uniform(s->key, s->slot++); }
 
 // ----------------------------------------------------------------------------
 // bsdf.h:29-69
@@ -723,13 +737,13 @@ inline vec3 tracePathAlternative(Shape* const* scene, int n_objects, ray& r, pt_
             float p_reflect, p_refract;
             SmoothDielectric::probabilities(r, min_p, material, &p_reflect, &p_refract);
             bool transmission;
-            float u = (p_reflect == 0.0f && p_refract == 0.0f) ? 0.0f : rng_to_uniform(rng_bits(key, slot));
+            float u = (p_reflect == 0.0f && p_refract == 0.0f) ? 0.0f : rng_slot_uniform(key, slot);
             newDirection = SmoothDielectric::sampleBSDF(r, min_p, p_reflect, p_refract, u, &transmission).normalized();
             f = SmoothDielectric::evalBSDF(material);
             pdf = SmoothDielectric::EvalPDF(transmission, p_refract);
         } else {
-            float u1 = rng_to_uniform(rng_bits(key, slot + 1u));
-            float u2 = rng_to_uniform(rng_bits(key, slot + 2u));
+            float u1 = rng_slot_uniform(key, slot + 1u);
+            float u2 = rng_slot_uniform(key, slot + 2u);
             newDirection = Lambertian::sampleBSDF(r, min_p, material, u1, u2).normalized();
             f = Lambertian::evalBSDF(r, newDirection, min_p, material);
             pdf = Lambertian::EvalPDF(r, newDirection, min_p, material);
@@ -737,7 +751,7 @@ inline vec3 tracePathAlternative(Shape* const* scene, int n_objects, ray& r, pt_
         if (pdf > 0.0f) coefficient = coefficient.cwiseProduct(f / pdf);
         else break;
         float p = fmaxf(coefficient.x(), fmaxf(coefficient.y(), coefficient.z()));
-        float u = rng_to_uniform(rng_bits(key, slot + 5u));
+        float u = rng_slot_uniform(key, slot + 5u);
         if (p < u) break;
         coefficient = coefficient * (1 / p);
         r = ray(newPosition, newDirection);

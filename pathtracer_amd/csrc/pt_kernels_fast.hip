@@ -93,6 +93,15 @@ PTD float rng_u(uint32_t key, uint32_t slot) {
     return __builtin_fmaf((float)bits, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
 }
 
+// The two coordinates of a point (pixel jitter; u1, u2 of a direction) come from the 16-bit halves of ONE hash, the
+// one of the pair's first slot: cell centres of 65 536 levels each.  One hash and two conversions instead of two
+// hashes (a hash is 3 slow-class multiplies among 9 integer instructions).
+PTD void rng_pair(uint32_t key, uint32_t first, float& a, float& b) {
+    const uint32_t bits = rng_hash(key ^ (0x85EBCA6Bu * (first + 1u)));
+    a = __builtin_fmaf((float)(bits >> 16), 1.52587890625e-05f, 7.62939453125e-06f);
+    b = __builtin_fmaf((float)(bits & 0xffffu), 1.52587890625e-05f, 7.62939453125e-06f);
+}
+
 constexpr float EPS = 1e-5f;   // SMALL_NUMBER (vec_math.h:7) as the float predicate t <= 1e-5
 
 struct Best {
@@ -657,7 +666,9 @@ PTD bool shade_scatter(Path& p, const Surf& s, const DMat& M, float t, bool hit,
         V3 rd = unit_or_zero(refract(p.d, s.nrm, eta));          // .normalized() of the zero vector is the zero vector
         const float rr = M.refractionRoughness * M.refractionRoughness;
         if (rr != 0.0f) {
-            const V3 hd = unit(s.nrm + sphere_point(rng_u(p.key, slot + 3u), rng_u(p.key, slot + 4u)));
+            float r1, r2;
+            rng_pair(p.key, slot + 3u, r1, r2);
+            const V3 hd = unit(s.nrm + sphere_point(r1, r2));
             rd = unit(lerp3(rd, hd, rr));
         }
         ndir = rd;
@@ -667,7 +678,11 @@ PTD bool shade_scatter(Path& p, const Surf& s, const DMat& M, float t, bool hit,
         // bounce never reads it
         const float sr = M.specularRoughness * M.specularRoughness;
         V3 dd = v3(0.0f, 0.0f, 0.0f);
-        if (mode != 1 || sr != 0.0f) dd = unit(s.nrm + sphere_point(rng_u(p.key, slot + 1u), rng_u(p.key, slot + 2u)));
+        if (mode != 1 || sr != 0.0f) {
+            float u1, u2;
+            rng_pair(p.key, slot + 1u, u1, u2);
+            dd = unit(s.nrm + sphere_point(u1, u2));
+        }
         if (mode == 1) {
             V3 sd = unit(reflect(p.d, s.nrm));
             if (sr != 0.0f) sd = unit(lerp3(sd, dd, sr));
@@ -714,7 +729,9 @@ PTD bool path_shade(Path& p, const Best& b0, const FShade* shade, const DMat* ma
 // shade_scatter) come out with d, coef and seg unchanged and o moved to the hit position.
 PTD bool shade_diffuse(Path& p, const Surf& s, const DMat& M, bool hit, bool keep, int n_bounces) {
     const uint32_t slot = 2u + 6u * (uint32_t)p.seg;
-    const V3 dd = unit(s.nrm + sphere_point(rng_u(p.key, slot + 1u), rng_u(p.key, slot + 2u)));
+    float u1, u2;
+    rng_pair(p.key, slot + 1u, u1, u2);
+    const V3 dd = unit(s.nrm + sphere_point(u1, u2));
     V3 coef = p.coef * v3(M.albedo[0], M.albedo[1], M.albedo[2]);
     const float q = max3(coef.x, coef.y, coef.z);
     bool dead = !hit || q <= 0.0f;
@@ -768,7 +785,9 @@ PTD bool path_shade_alt(Path& p, const Best& b, const FShade* shade, const DMat*
         const float bb = N.x * N.y * a;
         const V3 ox = v3(__builtin_fmaf(sign * N.x * N.x, a, 1.0f), sign * bb, -sign * N.x);
         const V3 oy = v3(bb, __builtin_fmaf(N.y * N.y, a, sign), -N.y);
-        const V3 r = sphere_point(rng_u(p.key, slot + 1u), rng_u(p.key, slot + 2u));
+        float u1, u2;
+        rng_pair(p.key, slot + 1u, u1, u2);
+        const V3 r = sphere_point(u1, u2);
         ndir = unit_or_zero(madd(ox, r.x, madd(oy, r.y, N * r.z)));
         const float ndl = dot(N, ndir), ndv = -dot(N, p.d);
         if (!(ndl > 0.0f) || !(ndv > 0.0f)) return false;
@@ -889,7 +908,9 @@ struct FastTracer {
     static PTD void start(Path& p, const RenderArgs& a, FastCtx& c, uint32_t px, uint32_t, uint32_t sample) {
         const uint32_t kpx = __float_as_uint(c.pxt[128 + px]);
         p.key = rng_hash(kpx + 0x9E3779B9u * (sample + 1u));
-        const float sx = c.pxt[px] + rng_u(p.key, 0u), sy = c.pxt[64 + px] + rng_u(p.key, 1u);
+        float jx, jy;
+        rng_pair(p.key, 0u, jx, jy);
+        const float sx = c.pxt[px] + jx, sy = c.pxt[64 + px] + jy;
         const V3 cam = v3(a.cam[0], a.cam[1], a.cam[2]);
         const V3 pc = v3(__builtin_fmaf(a.du, sx, a.p00[0]), __builtin_fmaf(a.dv, sy, a.p00[1]), a.p00[2]);
         p.o = cam;
@@ -903,7 +924,9 @@ struct FastTracer {
     static PTD void make_ray(const RenderArgs& a, FastCtx& c, uint32_t px, uint32_t, uint32_t sample, float4& ray) {
         const uint32_t kpx = __float_as_uint(c.pxt[128 + px]);
         const uint32_t key = rng_hash(kpx + 0x9E3779B9u * (sample + 1u));
-        const float sx = c.pxt[px] + rng_u(key, 0u), sy = c.pxt[64 + px] + rng_u(key, 1u);
+        float jx, jy;
+        rng_pair(key, 0u, jx, jy);
+        const float sx = c.pxt[px] + jx, sy = c.pxt[64 + px] + jy;
         const V3 cam = v3(a.cam[0], a.cam[1], a.cam[2]);
         const V3 pc = v3(__builtin_fmaf(a.du, sx, a.p00[0]), __builtin_fmaf(a.dv, sy, a.p00[1]), a.p00[2]);
         const V3 d = unit(pc - cam);

@@ -129,7 +129,7 @@ __global__ void rng_kernel(uint32_t seed_hash, uint32_t pixel, uint32_t sample, 
     const uint32_t key = rng_key(seed_hash, pixel, sample);
     const uint32_t b = rng_bits(key, (uint32_t)k);
     if (bits) bits[k] = b;
-    if (u) u[k] = rng_to_uniform(b);
+    if (u) u[k] = rng_slot_uniform(key, (uint32_t)k);
 }
 
 }  // namespace

@@ -51,7 +51,19 @@ PTD uint32_t rng_key(uint32_t seed_hash, uint32_t pixel, uint32_t sample) {
 }
 PTD uint32_t rng_bits(uint32_t key, uint32_t slot) { return rng_hash(key ^ (0x85EBCA6Bu * (slot + 1u))); }
 PTD float rng_to_uniform(uint32_t bits) { return (float)bits * 2.3283064365386963e-10f + 1.1641532182693481e-10f; }
-PTD float rng_u(uint32_t key, uint32_t slot) { return rng_to_uniform(rng_bits(key, slot)); }
+PTD float rng_u(uint32_t key, uint32_t slot) { return rng_to_uniform(rng_bits(key, slot)); }      // a draw that decides a branch: 32 bits
+// The two coordinates of a point (pixel jitter; u1, u2 of a direction) share the bits of the first slot of their pair,
+// 16 bits each, cell centres: (0, 1) in 65 536 levels.
+PTD float rng_half(uint32_t h16) { return (float)h16 * 1.52587890625e-05f + 7.62939453125e-06f; }
+PTD float rng_u_first(uint32_t key, uint32_t first) { return rng_half(rng_bits(key, first) >> 16); }
+PTD float rng_u_second(uint32_t key, uint32_t first) { return rng_half(rng_bits(key, first) & 0xffffu); }
+// The uniform of slot k under the slot map (0,1 jitter; 2+6s+{0 mode, 1,2 and 3,4 pairs, 5 roulette}).
+PTD float rng_slot_uniform(uint32_t key, uint32_t k) {
+    const uint32_t j = k < 2u ? k + 1u : (k - 2u) % 6u;
+    if (j == 1u || j == 3u) return rng_u_first(key, k);
+    if (j == 2u || j == 4u) return rng_u_second(key, k - 1u);
+    return rng_u(key, k);
+}
 
 // ---- local-space shape tests -------------------------------------------------
 // Surface codes let the winner's normal be rebuilt later without carrying it.
@@ -359,12 +371,12 @@ PTD bool path_step(Path& p, const DPrim* __restrict__ prims, int n_prims, const 
         V3 rd = normalized(refract(p.d, h.nrm, h.inside ? ior : 1.0f / ior));
         float rr = M.refractionRoughness * M.refractionRoughness;
         if (rr != 0.0f) {
-            V3 hd = normalized(h.nrm + sample_hemisphere(rng_u(p.key, slot + 3u), rng_u(p.key, slot + 4u)));
+            V3 hd = normalized(h.nrm + sample_hemisphere(rng_u_first(p.key, slot + 3u), rng_u_second(p.key, slot + 3u)));
             rd = lerp3(rd, hd, rr);
         }
         ndir = normalized(rd);
     } else {
-        V3 dd = normalized(h.nrm + sample_hemisphere(rng_u(p.key, slot + 1u), rng_u(p.key, slot + 2u)));
+        V3 dd = normalized(h.nrm + sample_hemisphere(rng_u_first(p.key, slot + 1u), rng_u_second(p.key, slot + 1u)));
         if (mode == 1) {
             V3 sd = normalized(reflect(p.d, h.nrm));
             float sr = M.specularRoughness * M.specularRoughness;
@@ -430,7 +442,7 @@ PTD bool path_step_alt(Path& p, const DPrim* __restrict__ prims, int n_prims, co
         f = v3(M.specularColor[0], M.specularColor[1], M.specularColor[2]);
         pdf = transmission ? pt : 1 - pt;
     } else {                                                                    // Lambertian, :74-114
-        float u1 = rng_u(p.key, slot + 1u), u2 = rng_u(p.key, slot + 2u);
+        float u1 = rng_u_first(p.key, slot + 1u), u2 = rng_u_second(p.key, slot + 1u);
         V3 ox, oy;
         construct_onb(h.nrm, &ox, &oy);
         V3 res = sample_hemisphere(u1, u2);
@@ -459,7 +471,7 @@ PTD bool path_step_alt(Path& p, const DPrim* __restrict__ prims, int n_prims, co
 
 // Camera ray of (pixel i,j; sample) exactly as render builds it (main.cu:62-64).
 PTD void camera_ray(const RenderArgs& a, int i, int j, uint32_t key, V3* o, V3* d) {
-    float jx = rng_u(key, 0u), jy = rng_u(key, 1u);
+    float jx = rng_u_first(key, 0u), jy = rng_u_second(key, 0u);
     float sx = (i - 0.5f + jx), sy = (a.max_y - j - 0.5f + jy);
     V3 pc = v3((a.p00[0] + a.du * sx) + 0.0f * sy, (a.p00[1] + 0.0f * sx) + a.dv * sy, (a.p00[2] + 0.0f * sx) + 0.0f * sy);
     V3 cam = v3(a.cam[0], a.cam[1], a.cam[2]);

@@ -83,6 +83,20 @@ def test_rng_range_and_golden(oracle):
     u = np.concatenate([ob.rng(3, p, 0, 256)[1] for p in range(64)])
     assert u.min() > 0.0 and u.max() <= 1.0
     assert abs(u.mean() - 0.5) < 0.01
+    # slot map: a branch decision takes the 32 bits of its slot, the coordinates of a point the 16-bit halves of the
+    # pair's first slot (jitter 0,1; segment s: 2+6s+{1,2} and 2+6s+{3,4})
+    bits, u = ob.rng(5, 77, 3, 62)
+    half = lambda h: np.float32(h) * np.float32(2.0 ** -16) + np.float32(2.0 ** -17)
+    wide = lambda b: np.float32(b) * np.float32(2.0 ** -32) + np.float32(2.0 ** -33)
+    for k in range(62):
+        j = k + 1 if k < 2 else (k - 2) % 6
+        want = half(bits[k] >> 16) if j in (1, 3) else (half(bits[k - 1] & 0xffff) if j in (2, 4) else wide(bits[k]))
+        assert u[k] == want, (k, j)
+    # the halves are uniform too, and the two coordinates of a point are not correlated
+    bits, u = zip(*[ob.rng(9, p, s, 8) for p in range(128) for s in range(16)])
+    u = np.array(u)
+    assert abs(u[:, 3].mean() - 0.5) < 0.02 and abs(u[:, 4].mean() - 0.5) < 0.02
+    assert abs(np.corrcoef(u[:, 3], u[:, 4])[0, 1]) < 0.06 and abs(np.corrcoef(u[:, 0], u[:, 1])[0, 1]) < 0.06
 
 
 def test_raypath_golden(oracle):

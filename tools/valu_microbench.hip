@@ -101,6 +101,21 @@ constexpr int ITERS = 10000;        // 10000 * 64 = 640000 instructions per wave
                  "v_cndmask_b32 %4, %4, %8, vcc\n\tv_cndmask_b32 %5, %5, %9, vcc\n\tv_fma_f32 %6, %6, %8, %9\n\tv_fma_f32 %7, %7, %8, %9"     \
                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
 
+// 64-bit compare into an SGPR pair: the (distance, index) rule of the primitive tests
+#define OPCMP64 \
+    asm volatile("v_cmp_lt_u64_e64 %4, %0, %5\n\tv_cmp_lt_u64_e64 %4, %1, %5\n\tv_cmp_lt_u64_e64 %4, %2, %5\n\tv_cmp_lt_u64_e64 %4, %3, %5\n\t" \
+                 "v_cmp_lt_u64_e64 %4, %0, %5\n\tv_cmp_lt_u64_e64 %4, %1, %5\n\tv_cmp_lt_u64_e64 %4, %2, %5\n\tv_cmp_lt_u64_e64 %4, %3, %5"     \
+                 : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "=s"(m) : "v"(qb));
+#define Q64PRE unsigned long long q0 = threadIdx.x, q1 = q0 + 1, q2 = q0 + 2, q3 = q0 + 3, qb = (unsigned long long)(seed * 3.0f);
+#define OPREADLANE \
+    asm volatile("v_readlane_b32 %8, %0, 3\n\tv_readlane_b32 %8, %1, 5\n\tv_readlane_b32 %8, %2, 7\n\tv_readlane_b32 %8, %3, 9\n\t" \
+                 "v_readlane_b32 %8, %4, 11\n\tv_readlane_b32 %8, %5, 13\n\tv_readlane_b32 %8, %6, 15\n\tv_readlane_b32 %8, %7, 17"     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=s"(mi));
+#define OPREADFIRST \
+    asm volatile("v_readfirstlane_b32 %8, %0\n\tv_readfirstlane_b32 %8, %1\n\tv_readfirstlane_b32 %8, %2\n\tv_readfirstlane_b32 %8, %3\n\t" \
+                 "v_readfirstlane_b32 %8, %4\n\tv_readfirstlane_b32 %8, %5\n\tv_readfirstlane_b32 %8, %6\n\tv_readfirstlane_b32 %8, %7"     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=s"(mi));
+
 typedef float float2v __attribute__((ext_vector_type(2)));
 #define PKPRE float2v p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pb = {b, b}, pc = {c, c};
 
@@ -140,6 +155,12 @@ KERNEL(bfe_u32, OP3("v_bfe_u32"), )
 KERNEL(cndmask_sgpr, OPCNDMASK_S, )
 KERNEL(cndmask_2src, OPCNDMASK_2, )
 KERNEL(cmp_sel_mix, OPCMPSEL, )
+KERNEL(cmp_lt_u64, OPCMP64, Q64PRE)
+KERNEL(readlane, OPREADLANE, int mi = 0; (void)mi)
+KERNEL(readfirstlane, OPREADFIRST, int mi = 0; (void)mi)
+KERNEL(cvt_u32_f32, OP1("v_cvt_u32_f32"), )
+KERNEL(floor, OP1("v_floor_f32"), )
+KERNEL(mbcnt, OP2("v_mbcnt_lo_u32_b32"), )
 KERNEL(salu, OPSALU, )
 KERNEL(mix_fma_salu, OPMIX, )
 
@@ -169,7 +190,7 @@ int main() {
         E(fma), E(mul), E(add), E(sub), E(fmac), E(mov), E(xor), E(and), E(lshrrev), E(add_u32), E(fma_sgpr), E(mul_sgpr),
         E(max), E(min), E(max3), E(med3), E(cmp_vcc), E(cmp_sgpr), E(cndmask_sgpr), E(cndmask), E(cndmask_2src), E(cmp_sel_mix),
         E(mul_lo_u32), E(mul_hi_u32), E(mad_u32_u24), E(mul_u32_u24), E(xad_u32), E(lshl_add_u32), E(alignbit), E(bfe_u32),
-        E(cvt_f32_u32), E(pk_fma), E(rcp), E(rsq), E(sqrt), E(sin), E(exp), E(salu), E(mix_fma_salu)};
+        E(cvt_f32_u32), E(cvt_u32_f32), E(floor), E(cmp_lt_u64), E(readlane), E(readfirstlane), E(mbcnt), E(pk_fma), E(rcp), E(rsq), E(sqrt), E(sin), E(exp), E(salu), E(mix_fma_salu)};
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
