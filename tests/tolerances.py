@@ -27,8 +27,8 @@ FAST = {
     "nearest_prim_mismatch": 5e-3,  # rays naming another primitive (measured 2e-3): re-hits of the surface a grazing ray
     "rehit_t": 1e-2,                # leaves, at a distance below rehit_t, ties within t_rel_max, and
     "nearest_grazing": 5e-4,        # grazing hits of small shapes (measured: 1 ray of 4096 on the 10 000-primitive scene)
-    "image_rmse_at_1spp": 0.16,   # fast_image_rmse(spp) = this / sqrt(spp); measured x sqrt(spp): 0.074 (256x256@16, 1.85 %),
-                                  # 0.103 (1080p@64, 1.29 %), 0.126 (rows of 4K@1024, 0.39 %)
+    "image_rmse_at_1spp": 0.16,   # fast_image_rmse(spp) = this / sqrt(spp); measured x sqrt(spp): 0.086 (256x256@16, 2.1 %),
+                                  # 0.110 (1080p@64, 1.37 %), 0.085 (every 400th row of 4K@1024, 0.27 %)
     "bad_pixel_frac": 3e-3,       # measured 1.0e-3 at 1080p@64
     "mean_rel": 0.005,            # per-channel mean radiance of one frame (converged-statistics bound)
     "bias_mean_rel": 0.001,       # per-channel mean of the seed-averaged difference to the parity-order kernel
@@ -44,8 +44,8 @@ FAST = {
 # discriminant b^2 - c cancel to r^2/D^2 of its terms, in the reference's local frame as much as here, so two correct
 # float evaluations differ by hundreds of ULPs on small far shapes and by more at grazing incidence.  Measured
 # (median / p99 / max): default scene 1 / 24 / 421, general kinds 0 / 5 / 224, glass grid 1 / 73 / 735, rotated
-# cylinders-ellipsoids-cubes 1 / 27 / 1377, 10 000 small shapes 1 / 582 / 5222.  Positions relative to the largest
-# coordinate: 3.3e-5 default, 4.0e-4 small shapes; normals (99th percentile, per component): 7.7e-6 and 5.6e-3 (a
+# cylinders-ellipsoids-cubes 1 / 27 / 1377, 10 000 small shapes 1 / 238 / 2825.  Positions relative to the largest
+# coordinate: 3.3e-5 default, 2.2e-4 small shapes; normals (99th percentile, per component): 7.7e-6 and 1.8e-3 (a
 # position error divided by the radius).
 FAST_NEAREST = {
     "default": {"t_ulp_median": 1, "t_ulp_p99": 64, "t_ulp_max": 1024, "pos_rel_max": 1e-4, "nrm_abs_p99": 1e-4},
