@@ -162,7 +162,12 @@ template <int N, class RP> PTD void test_plane_axis(RP R, V3 o, V3 d, V3 inv, in
 // + getNearestIntersection keep is the smaller one if it is beyond EPS, else the
 // larger.  A negative discriminant makes s NaN and every compare false.
 PTD void take_quadratic(float a, float ia, float h, float c, int id, Best& b) {
-    const float s = fsqrt(__builtin_fmaf(h, h, -a * c));
+    const float disc = __builtin_fmaf(h, h, -a * c);
+#ifndef PT_NO_QUADRATIC_SKIP
+    // most waves miss a small shape with every lane: the roots, the choice between them and the compare are then skipped
+    if (__ballot(disc >= 0.0f) == 0ull) return;
+#endif
+    const float s = fsqrt(disc);
     const float t1 = (-h - s) * ia, t2 = (s - h) * ia;
     const float t = t1 > EPS ? t1 : t2;
     const bool ok = (t > EPS) & nearer(t, id, b);
