@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--general-kinds", action="store_true",
                     help="upload the scene with the general record kinds only (what a scene with rotated shapes gets); not the headline")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: gather each frame before rendering the next")
+    ap.add_argument("--tile-log2", type=int, default=-1, help="pixels per wave as a power of two (development aid; default: this script's choice)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="development aid on one GPU: render rank 0's share of an N-GPU run with the N-GPU pipeline, no collectives")
     args = ap.parse_args()
@@ -192,10 +193,13 @@ def main():
     my_rows = len(multigpu.rank_rows(HEIGHT, rank, part))
     # PT_BENCH_FORCE_OVERLAP=1 exercises the pipeline on one GPU (development aid)
     overlap = (part > 1 or os.environ.get("PT_BENCH_FORCE_OVERLAP") == "1") and not args.no_overlap
-    # Launches in flight on alternating streams fill each other's tails, so large tiles (less drain per wave) pay:
-    # measured per rank share of this frame, 64 pixels per wave from 0.4 Mpixel, 32 below (the library's own choice,
-    # 16 or 8 pixels, suits a launch that has the GPU to itself).  The image does not depend on the tile size.
-    tile_log2 = (6 if my_rows * WIDTH >= 400000 else 5) if overlap else 0
+    # Launches in flight on alternating streams fill each other's tails, so larger tiles than a lone launch wants (less
+    # drain per wave) pay: measured per rank share of this frame with 32 pixels per wave / the library's own choice
+    # (16 or 8 pixels below 0.9 Mpixel): N=2 1.343 / 1.341 ms, N=4 0.690 / 0.729, N=8 0.361 / 0.378 (64 pixels: 1.468
+    # at N=2).  The image does not depend on the tile size.
+    tile_log2 = 5 if overlap else 0
+    if args.tile_log2 >= 0:
+        tile_log2 = args.tile_log2
     cfg = pt.make_config(WIDTH, HEIGHT, SPP, n_bounces=DEPTH, seed=SEED, row_begin=rank, row_end=HEIGHT, row_step=part,
                          fb_compact=1, math_mode=math_mode, tile_log2=tile_log2)
     frames = [multigpu.TiledFrame(HEIGHT, WIDTH, part, device, collective=not emulate) for _ in range(2 if overlap else 1)]

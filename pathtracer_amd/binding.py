@@ -256,7 +256,7 @@ class Scene:
         return self
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:      # at interpreter shutdown the module's globals may be gone
             lib.pt_scene_free(self.h)
             self.h = None
 

@@ -732,10 +732,11 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     // 1080p frame and its interleaved row sets: 32 is best from 1.5 Mpixel, 16 from 0.2 Mpixel, 8 below, 64 only
     // for frames several times 1080p.  The image does not depend on this choice (pixel sums are exact
     // fixed-point sums).
-    // The loop with camera batches keeps 32 up to the largest frames (3840x2160 @ 1024: 181 ms against 202 with 64).
+    // The loop with camera batches keeps 32 up to the largest frames (3840x2160 @ 1024: 181 ms against 202 with 64) and
+    // takes it from 0.9 Mpixel (half a 1080p frame: 1.479 ms against 1.508 with 16; a third: 1.040 against 1.024).
     const bool batched = cfg->math_mode == PT_MATH_FAST && cfg->bsdf_model == PT_BSDF_REFERENCE && sc->n_bnodes == 0 &&
                          sc->tune[PT_TUNE_GLASS_QUEUE] >= 0;
-    a.tile_log2 = (a.n_lin >= 6000000u && !batched) ? 6 : (a.n_lin >= 1500000u ? 5 : (a.n_lin >= 200000u ? 4 : 3));
+    a.tile_log2 = (a.n_lin >= 6000000u && !batched) ? 6 : (a.n_lin >= (batched ? 900000u : 1500000u) ? 5 : (a.n_lin >= 200000u ? 4 : 3));
     // ... and a pool of at least ~2048 samples per wave, or the drain phase dominates at low sample counts (10 000
     // primitives, 1080p, 4 spp: 263 ms with 32 pixels per wave, 216 ms with 64) — as long as that leaves two waves
     // for every wave slot of the chip.
