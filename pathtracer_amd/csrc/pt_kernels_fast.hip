@@ -163,7 +163,7 @@ template <int N, class RP> PTD void test_plane_axis(RP R, V3 o, V3 d, V3 inv, in
 // larger.  A negative discriminant makes s NaN and every compare false.
 PTD void take_quadratic(float a, float ia, float h, float c, int id, Best& b) {
     const float disc = __builtin_fmaf(h, h, -a * c);
-#ifndef PT_NO_QUADRATIC_SKIP
+#ifndef PT_NO_QUADRATIC_SKIP          // (measurement aid)
     // most waves miss a small shape with every lane: the roots, the choice between them and the compare are then skipped
     if (__ballot(disc >= 0.0f) == 0ull) return;
 #endif
@@ -715,11 +715,6 @@ PTD bool shade_scatter(Path& p, const Surf& s, const DMat& M, float t, bool hit,
 // The whole loop body: surface record and material of the winner, then the two parts above.
 PTD bool path_shade(Path& p, const Best& b0, const FShade* shade, const DMat* mats, int n_bounces, PhaseClock& clk) {
     const bool hit = b0.id >= 0;
-#ifdef PT_DEBUG_KEYS
-    { const uint32_t dk[] = {PT_DEBUG_KEYS};
-      for (uint32_t q : dk) if (p.key == q) printf("DBG key %08x seg %d o %08x %08x %08x d %08x %08x %08x t %08x (%g) id %d\n", p.key, p.seg,
-          __float_as_uint(p.o.x), __float_as_uint(p.o.y), __float_as_uint(p.o.z), __float_as_uint(p.d.x), __float_as_uint(p.d.y), __float_as_uint(p.d.z), __float_as_uint(b0.t), b0.t, b0.id); }
-#endif
     Best b = b0;
     b.id = hit ? b0.id : 0;                            // a miss reads primitive 0's records and is dropped at the end
     const Surf s = surface(b, p.o, p.d, shade);
@@ -1196,11 +1191,7 @@ PTD void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds&
     const uint32_t lin_base = tile << lg;
     const uint32_t npx = min(P, a.n_lin - lin_base);
     const uint32_t total = (uint32_t)a.n_samples << lg;
-#ifdef PT_CONST_Q
-    constexpr uint32_t QC = 24, QG = 18, QI = 8;
-#else
     const uint32_t QC = (uint32_t)a.q_cap, QG = (uint32_t)a.q_gate, QI = (uint32_t)a.q_inline;
-#endif
 
     for (uint32_t k = lane; k < 3u * P; k += 64u) L.acc[k] = 0ull;
     if (lane < npx) {
@@ -1208,13 +1199,10 @@ PTD void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds&
         L.out_px[lane] = ref.out;
         T::prologue(a, ctx, lane, ref);
     }
-#ifdef PT_NO_CULL
+#ifdef PT_NO_CULL                    // measurement aid: camera rays test every record
     const unsigned long long cand = ~0ull;
 #else
     const unsigned long long cand = tile_candidates(a, lin_base, npx, lane);
-#endif
-#ifdef PT_DEBUG_CAND
-    if (lane == 0 && (tile % 4001u) == 0u) printf("tile %u lin_base %u cand %016llx\n", tile, lin_base, cand);
 #endif
 
     ptf::Path path;
@@ -1263,7 +1251,7 @@ PTD void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds&
                 if (parked == 0u) {
                     if (made >= total) break;
                     parked = camera_batch<SORTED, KM>(a, ctx, L, sc, cand, made, total, lin_base, npx, lane);
-#ifdef PT_BATCH_ONLY
+#ifdef PT_BATCH_ONLY                 // measurement aid: camera batches alone (what they park is dropped)
                     parked = 0;
 #endif
                     made = min(made + 64u, total);
