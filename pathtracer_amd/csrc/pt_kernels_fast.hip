@@ -821,11 +821,11 @@ struct SceneRefs {
 };
 
 // One iteration of the tracePath loop (bsdf.h:78-166); true = continue.
-template <bool BVH, bool SORTED>
+template <bool BVH, bool SORTED, int KM = KM_ALL>
 PTD bool path_step(Path& p, const SceneRefs& sc, const FShade* shade, const DMat* mats, int n_bounces, int bsdf_model, PhaseClock& clk) {
     Best b = best_none();
     const float dd = dot(p.d, p.d), idd = rcp(dd);
-    if (SORTED) scan_sorted(p.o, p.d, dd, idd, sc.sorted, b);
+    if (SORTED) scan_sorted<KM>(p.o, p.d, dd, idd, sc.sorted, b);
     else scan_runs(p.o, p.d, dd, idd, as_constant(sc.fdata), as_constant(sc.runs), 0, sc.n_runs, b);
     if (BVH) { int n = 0; walk_hierarchy(p.o, p.d, dd, idd, sc.nodes, sc.n_nodes, sc.bprims, b, n, 0x7fffffff); }
     PHASE(clk, 1);
@@ -893,7 +893,7 @@ struct FastCtx {
 
 // BVH: 0 = loop over all primitives, 1 = hierarchy in skip-link form, 2 = hierarchy in fat form.
 // SORTED: the loop runs over the kind-sorted records (PT_MATH_FAST) instead of the runs in scene order.
-template <int BVH, bool SORTED>
+template <int BVH, bool SORTED, int KM = KM_ALL>
 struct FastTracer {
     using Path = typename std::conditional<BVH != 0, ptf::WalkPath, ptf::Path>::type;
     // The hierarchy walk counts lanes (shade gate), so there only lanes with a path step.
@@ -950,7 +950,7 @@ struct FastTracer {
         return step_path(p, sc, a, c);
     }
     static PTD bool step_path(ptf::Path& p, const SceneRefs& sc, const RenderArgs& a, FastCtx& c) {
-        return path_step<false, SORTED>(p, sc, c.shade, c.mats, a.n_bounces, a.bsdf_model, c.clk);
+        return path_step<false, SORTED, KM>(p, sc, c.shade, c.mats, a.n_bounces, a.bsdf_model, c.clk);
     }
     static PTD bool step_path(ptf::WalkPath& p, const SceneRefs& sc, const RenderArgs& a, FastCtx& c) {
         return path_step_walk<BVH == 2>(p, sc, c.shade, c.mats, a.n_bounces, a.bsdf_model, a.walk_budget, a.shade_gate, c.wstack, c.clk);
@@ -1400,7 +1400,7 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_batched_kernel(RenderA
     ctx.clk.flush(threadIdx.x & 63);
 }
 
-template <bool LDS_TABLES, int BVH, bool SORTED>
+template <bool LDS_TABLES, int BVH, bool SORTED, int KM = KM_ALL>
 __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, uint32_t n_tiles) {
     __shared__ ptw::WaveLds lds[ptw::WAVES_PER_BLOCK];
     __shared__ float pxt[ptw::WAVES_PER_BLOCK][192];
@@ -1428,7 +1428,7 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, u
     ctx.pxt = pxt[wave];
     ctx.wstack = BVH == 2 ? wstack + wave * ((uint32_t)a.walk_stack * 64u) + (threadIdx.x & 63u) : nullptr;
     ctx.clk.start();
-    ptw::render_tile<FastTracer<BVH, SORTED>>(a, tile, lds[wave], stash[wave], ctx);
+    ptw::render_tile<FastTracer<BVH, SORTED, KM>>(a, tile, lds[wave], stash[wave], ctx);
     ctx.clk.flush(threadIdx.x & 63);
 }
 
@@ -1551,22 +1551,24 @@ int ptk_render_fast(const RenderArgs& a, int variant, hipStream_t s) {
     } else {
         const bool tables = a.n_prims <= LDS_MAX_PRIMS && a.n_mats <= LDS_MAX_MATS;
         const bool sorted = variant == PT_MATH_FAST;   // PT_MATH_FAST_SCALAR: the runs, in scene order, plain loop
+        // a table that holds short kinds only (or general kinds only) gets the loop without the others' code
+        int kinds = 0;
+        for (int k = 0; k < FP_KINDS; k++) if (a.sorted.count[k] > 0) kinds |= 1 << k;
+        const bool short_only = (kinds & ~KM_SHORT) == 0, general_only = (kinds & ~KM_GENERAL) == 0;
         if (sorted && a.q_cap > 0) {
             // The loop with camera batches and the glass queue.  All of its LDS is dynamic: per-wave arrays sized by the tile, the
             // queue by q_cap, the tables by the scene.
             const size_t table_bytes = tables ? (size_t)a.n_prims * sizeof(FShade) + (size_t)a.n_mats * sizeof(DMat) : 0;
             const size_t lds = batched_wave_bytes(1u << a.tile_log2, (uint32_t)a.q_cap) * ptw::WAVES_PER_BLOCK + table_bytes;
-            // a table that holds short kinds only gets the loop without the others' code
-            int kinds = 0;
-            for (int k = 0; k < FP_KINDS; k++) if (a.sorted.count[k] > 0) kinds |= 1 << k;
-            const bool short_only = (kinds & ~KM_SHORT) == 0, general_only = (kinds & ~KM_GENERAL) == 0;
 #define PT_LAUNCH_BATCHED(T, KM) hipLaunchKernelGGL((render_fast_batched_kernel<T, true, KM>), dim3(blocks), dim3(ptw::BLOCK), lds, s, a, n_tiles)
             if (tables) { if (short_only) PT_LAUNCH_BATCHED(true, KM_SHORT); else if (general_only) PT_LAUNCH_BATCHED(true, KM_GENERAL); else PT_LAUNCH_BATCHED(true, KM_ALL); }
             else { if (short_only) PT_LAUNCH_BATCHED(false, KM_SHORT); else if (general_only) PT_LAUNCH_BATCHED(false, KM_GENERAL); else PT_LAUNCH_BATCHED(false, KM_ALL); }
 #undef PT_LAUNCH_BATCHED
         } else if (sorted) {
-            if (tables) hipLaunchKernelGGL((render_fast_kernel<true, 0, true>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
-            else hipLaunchKernelGGL((render_fast_kernel<false, 0, true>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+#define PT_LAUNCH_PLAIN(T, KM) hipLaunchKernelGGL((render_fast_kernel<T, 0, true, KM>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles)
+            if (tables) { if (short_only) PT_LAUNCH_PLAIN(true, KM_SHORT); else if (general_only) PT_LAUNCH_PLAIN(true, KM_GENERAL); else PT_LAUNCH_PLAIN(true, KM_ALL); }
+            else { if (short_only) PT_LAUNCH_PLAIN(false, KM_SHORT); else if (general_only) PT_LAUNCH_PLAIN(false, KM_GENERAL); else PT_LAUNCH_PLAIN(false, KM_ALL); }
+#undef PT_LAUNCH_PLAIN
         } else {
             if (tables) hipLaunchKernelGGL((render_fast_kernel<true, 0, false>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
             else hipLaunchKernelGGL((render_fast_kernel<false, 0, false>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
