@@ -129,3 +129,20 @@ def test_tune_rejects_bad_values(pt):
                       (b.PT_TUNE_SHADE_GATE, 65), (b.PT_TUNE_BVH_WALK, 2), (99, 1), (-1, 1)):
         assert b.lib.pt_scene_tune(sc.h, knob, bad) != 0
         assert b"pt_scene_tune" in b.lib.pt_last_error()
+
+
+def test_every_compiled_kind_set_equals_the_run_table_loop(torch, pt):
+    """The loops are compiled per set of record kinds (short kinds only, general kinds only, all kinds with offsets and
+    counts read from the head of the record buffer); each must give the image of the loop over the run table in scene
+    order, bit for bit, with the batched loop and with the plain one."""
+    from pathtracer_amd import binding as b
+    for general in (0, b.PT_GENERAL_ALL, b.PT_GENERAL_PLANES, b.PT_GENERAL_CUBES, b.PT_GENERAL_SPHERES, b.PT_GENERAL_PLANES | b.PT_GENERAL_SPHERES):
+        for scene_data, depth in ((pt.default_scene(), 5), (pt.glass_grid_scene(3), 12)):
+            sc = pt.Scene(*scene_data, general_kinds=general)
+            for model in (pt.PT_BSDF_REFERENCE, pt.PT_BSDF_CLASSES):        # the class-based model runs the plain loop
+                cfg = lambda mode: pt.make_config(210, 118, 6, n_bounces=depth, math_mode=mode, bsdf_model=model)
+                ref = sc.render(cfg(pt.PT_MATH_FAST_SCALAR))
+                assert torch.equal(sc.render(cfg(pt.PT_MATH_FAST)), ref), (general, depth, model)
+            sc.tune(b.PT_TUNE_GLASS_QUEUE, -1)
+            cfg = pt.make_config(210, 118, 6, n_bounces=depth, math_mode=pt.PT_MATH_FAST)
+            assert torch.equal(sc.render(cfg), sc.render(pt.make_config(210, 118, 6, n_bounces=depth, math_mode=pt.PT_MATH_FAST_SCALAR))), (general, "plain")
