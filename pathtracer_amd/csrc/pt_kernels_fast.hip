@@ -734,8 +734,9 @@ PTD bool shade_diffuse(Path& p, const Surf& s, const DMat& M, bool hit, bool kee
     const V3 dd = unit(s.nrm + sphere_point(u1, u2));
     V3 coef = p.coef * v3(M.albedo[0], M.albedo[1], M.albedo[2]);
     const float q = max3(coef.x, coef.y, coef.z);
-    bool dead = !hit || q <= 0.0f;
-    if (!(q >= 1.0f)) dead = dead || rng_u(p.key, slot + 5u) > q;
+    // (the roulette draw is made for every lane: a diffuse albedo below 1 needs it nearly always, and a branch around
+    // eleven instructions costs more than it saves)
+    const bool dead = !hit | (q <= 0.0f) | (!(q >= 1.0f) & (rng_u(p.key, slot + 5u) > q));
     coef = coef * rcp(q);
     p.coef = v3(keep ? p.coef.x : coef.x, keep ? p.coef.y : coef.y, keep ? p.coef.z : coef.z);
     p.d = v3(keep ? p.d.x : dd.x, keep ? p.d.y : dd.y, keep ? p.d.z : dd.z);
@@ -1161,7 +1162,8 @@ PTD uint32_t camera_batch(const RenderArgs& a, FastCtx& ctx, const BatchLds& L, 
     p.o = o; p.d = d; p.coef = v3(1.0f, 1.0f, 1.0f); p.contrib = v3(0.0f, 0.0f, 0.0f); p.key = key; p.seg = 0;
     shade_emissive(p, hit, M);
     const bool lit = (p.contrib.x != 0.0f) || (p.contrib.y != 0.0f) || (p.contrib.z != 0.0f);
-    const bool special = hit && ((M.f0 != 0.0f) || (M.transparency != 0.0f));
+    const float m_f0 = M.f0, m_tr = M.transparency;
+    const bool special = hit & ((m_f0 != 0.0f) | (m_tr != 0.0f));
     const V3 light = p.contrib;
     const bool go_on = shade_diffuse(p, s, M, hit, false, a.n_bounces);
     // a secondary ray carries no light of its own: a hit that is lit and goes on keeps its camera ray and is shaded
@@ -1322,7 +1324,9 @@ PTD void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds&
         const DMat& M = ctx.mats[s.material];
         PHASE(ctx.clk, 2);
         shade_emissive(path, hit, M);
-        const bool special = hit && st == ACTIVE && ((M.f0 != 0.0f) || (M.transparency != 0.0f) || (path.seg > 0 && s.inside));
+        // (plain & and |: both material fields are fetched at once instead of one behind a branch on the other)
+        const float m_f0 = M.f0, m_tr = M.transparency;
+        const bool special = hit & (st == ACTIVE) & ((m_f0 != 0.0f) | (m_tr != 0.0f) | ((path.seg > 0) & s.inside));
         // 5. hits that need the full shading: into the queue (the lane is free at once), or kept in registers
         const unsigned long long special_m = __ballot(special);
         bool keep = false;
