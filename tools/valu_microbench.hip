@@ -116,6 +116,16 @@ constexpr int ITERS = 10000;        // 10000 * 64 = 640000 instructions per wave
                  "v_readfirstlane_b32 %8, %4\n\tv_readfirstlane_b32 %8, %5\n\tv_readfirstlane_b32 %8, %6\n\tv_readfirstlane_b32 %8, %7"     \
                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=s"(mi));
 
+// the select pattern as the compiler emits it: the mask combined by the scalar unit into vcc, or into an SGPR pair
+#define OPSELVCC \
+    asm volatile("s_and_b64 vcc, %8, exec\n\tv_cndmask_b32 %0, %0, %9, vcc\n\tv_cndmask_b32 %1, %1, %9, vcc\n\tv_fma_f32 %2, %2, %9, %9\n\tv_fma_f32 %3, %3, %9, %9\n\t" \
+                 "s_and_b64 vcc, %8, exec\n\tv_cndmask_b32 %4, %4, %9, vcc\n\tv_cndmask_b32 %5, %5, %9, vcc\n\tv_fma_f32 %6, %6, %9, %9\n\tv_fma_f32 %7, %7, %9, %9"     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(m), "v"(b) : "vcc", "scc");
+#define OPSELSGPR \
+    asm volatile("s_and_b64 %10, %8, exec\n\tv_cndmask_b32_e64 %0, %0, %9, %10\n\tv_cndmask_b32_e64 %1, %1, %9, %10\n\tv_fma_f32 %2, %2, %9, %9\n\tv_fma_f32 %3, %3, %9, %9\n\t" \
+                 "s_and_b64 %10, %8, exec\n\tv_cndmask_b32_e64 %4, %4, %9, %10\n\tv_cndmask_b32_e64 %5, %5, %9, %10\n\tv_fma_f32 %6, %6, %9, %9\n\tv_fma_f32 %7, %7, %9, %9"     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(m), "v"(b), "s"(m2) : "scc");
+
 typedef float float2v __attribute__((ext_vector_type(2)));
 #define PKPRE float2v p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pb = {b, b}, pc = {c, c};
 
@@ -161,6 +171,8 @@ KERNEL(readfirstlane, OPREADFIRST, int mi = 0; (void)mi)
 KERNEL(cvt_u32_f32, OP1("v_cvt_u32_f32"), )
 KERNEL(floor, OP1("v_floor_f32"), )
 KERNEL(mbcnt, OP2("v_mbcnt_lo_u32_b32"), )
+KERNEL(sel_salu_vcc, OPSELVCC, m = 0x5555555555555555ull)
+KERNEL(sel_salu_sgpr, OPSELSGPR, m = 0x5555555555555555ull; unsigned long long m2 = 1; asm volatile("" : "+s"(m2)))
 KERNEL(salu, OPSALU, )
 KERNEL(mix_fma_salu, OPMIX, )
 
@@ -188,7 +200,7 @@ int main() {
     std::vector<Entry> ks = {
 #define E(n) {#n, k_##n}
         E(fma), E(mul), E(add), E(sub), E(fmac), E(mov), E(xor), E(and), E(lshrrev), E(add_u32), E(fma_sgpr), E(mul_sgpr),
-        E(max), E(min), E(max3), E(med3), E(cmp_vcc), E(cmp_sgpr), E(cndmask_sgpr), E(cndmask), E(cndmask_2src), E(cmp_sel_mix),
+        E(max), E(min), E(max3), E(med3), E(cmp_vcc), E(cmp_sgpr), E(cndmask_sgpr), E(cndmask), E(cndmask_2src), E(cmp_sel_mix), E(sel_salu_vcc), E(sel_salu_sgpr),
         E(mul_lo_u32), E(mul_hi_u32), E(mad_u32_u24), E(mul_u32_u24), E(xad_u32), E(lshl_add_u32), E(alignbit), E(bfe_u32),
         E(cvt_f32_u32), E(cvt_u32_f32), E(floor), E(cmp_lt_u64), E(readlane), E(readfirstlane), E(mbcnt), E(pk_fma), E(rcp), E(rsq), E(sqrt), E(sin), E(exp), E(salu), E(mix_fma_salu)};
     hipDeviceProp_t prop;
