@@ -175,6 +175,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     emulate = args.emulate_world if world == 1 else 0
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # PT_BENCH_REHEARSE=1: every rank on GPU 0 and the collectives through gloo, so that the whole N-rank flow (launcher,
+    # partition, gather, pipeline, bitwise check, reductions) can run on a box with one GPU.  Its rates mean nothing.
+    rehearse = os.environ.get("PT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -183,8 +188,17 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    debug = os.environ.get("PT_BENCH_DEBUG") == "1"
+
+    def note(msg):
+        if debug:
+            print("[bench rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)
+    note("process group ready")
     prims, n, mats, nm = pt.default_scene()
     scene = pt.Scene(prims, n, mats, nm, device=local_rank, general_kinds=pt.PT_GENERAL_ALL if args.general_kinds else 0)
     math_mode = {"fast": pt.PT_MATH_FAST, "parity": pt.PT_MATH_PARITY, "scalar": pt.PT_MATH_FAST_SCALAR, "lds": pt.PT_MATH_FAST_LDS}[args.math]
@@ -246,7 +260,9 @@ def main():
             rs.wait_stream(main_stream)      # scene upload and buffer fills were issued on the current stream
     for k in range(args.warmup):
         step(k)
+    note("warm-up issued")
     fence()
+    note("warm-up done")
     # Kernel time: HIP events on the stream pt_render launches on (torch's current stream), around the
     # render launch only, inside the timed region.
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -255,6 +271,7 @@ def main():
         step(args.warmup + k, ev[k])
     fence()
     elapsed = time.perf_counter() - t0
+    note("timed steps done")
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     image = frames[(args.warmup + args.steps - 1) % len(frames)].image
 
@@ -275,16 +292,18 @@ def main():
             torch.cuda.synchronize()
         fence()
         single_ms = (time.perf_counter() - ts) / n_single * 1e3
+        note("single frames done")
     if world > 1:
         # Rank 0 renders the whole frame alone (untimed) and compares the gathered image with it, bit for bit.
-        flag = torch.ones(1, dtype=torch.int32, device=device)
+        flag = torch.ones(1, dtype=torch.int32, device="cpu" if rehearse else device)
         if rank == 0:
             alone = scene.render(pt.make_config(WIDTH, HEIGHT, SPP, n_bounces=DEPTH, seed=SEED, math_mode=math_mode))
             flag[0] = 1 if torch.equal(alone, image) else 0
         dist.broadcast(flag, src=0)
         bitwise = bool(int(flag[0]))
+        note("bitwise check done")
 
-    t = torch.tensor([elapsed, kernel_ms, single_ms or 0.0], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed, kernel_ms, single_ms or 0.0], dtype=torch.float64, device="cpu" if rehearse else device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = float(t[0]), float(t[1])
@@ -314,7 +333,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "reference default scene (main.cu:73-195), 1920x1080, 64 spp, depth 5, seed 0"
                                    + (" [general record kinds only: not the headline]" if args.general_kinds else ""),
-                       "math_mode": args.math, "partition": "rows r, r+%d, ... per rank, all-gather + strided copy%s%s" % (part, ", gather of frame k overlapped with render of frame k+1, frames on alternating streams" if overlap else "", " [EMULATED rank 0 of %d on one GPU, no collectives]" % emulate if emulate else ""),
+                       "math_mode": args.math, "partition": "rows r, r+%d, ... per rank, all-gather + strided copy%s%s" % (part, ", gather of frame k overlapped with render of frame k+1, frames on alternating streams" if overlap else "", (" [EMULATED rank 0 of %d on one GPU, no collectives]" % emulate if emulate else "") + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearse else "")),
                        "flops_per_sample": fps},
             "roofline": {"bound": "valu_fp32", "kernel": kernel,
                          "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -42,7 +42,12 @@ class TiledFrame:
         """All-gather the local tiles and put the rows back in image order."""
         if self.world == 1:
             return self.image
-        if self.collective:
+        if self.collective and self.local.is_cuda and dist.get_backend(group) == "gloo":
+            # rehearsals of the N-rank flow on a box with one GPU: the gather goes through host memory
+            host = torch.empty(self.gathered.numel(), dtype=torch.float32)
+            dist.all_gather_into_tensor(host, self.local.reshape(-1).cpu(), group=group)
+            self.gathered.view(-1).copy_(host)
+        elif self.collective:
             dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=group)
         else:
             self.gathered.view(self.world, -1)[0].copy_(self.local.view(-1))
