@@ -184,11 +184,11 @@ PTD void take_quadratic(float a, float ia, float h, float c, int id, Best& b) {
 // bias on the rims of small bright spheres.)  dd = d.d and idd = 1/dd are the caller's.
 template <class RP> PTD void test_sphere_ws(RP R, V3 o, V3 d, float dd, float idd, int id, Best& b) {
     const float k = R[0];
-    V3 ol;
-    {
-#pragma clang fp contract(off)
-        ol = v3(o.x * k + R[1], o.y * k + R[2], o.z * k + R[3]);
-    }
+    // (the empty asm keeps product and sum apart: under -ffp-contract=fast the compiler fuses them even inside
+    // `#pragma clang fp contract(off)` and through __fmul_rn / __fadd_rn)
+    float mx = o.x * k, my = o.y * k, mz = o.z * k;
+    asm volatile("" : "+v"(mx), "+v"(my), "+v"(mz));
+    const V3 ol = v3(mx + R[1], my + R[2], mz + R[3]);
     take_quadratic(R[4] * dd, R[5] * idd, k * dot(d, ol), dot(ol, ol) - 0.25f, id, b);
 }
 
