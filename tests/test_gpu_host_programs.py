@@ -1,4 +1,4 @@
-"""GPU tests of the C++ host side: the reference-style shape tests compiled
+"""GPU tests of the C++ host side: the reference's known answers and the rest of the host API, compiled
 against include/pt/api.h, and the pathtracer program that reproduces the
 reference's main() flow (scene construction -> render -> PPM on stdout)."""
 import os
@@ -23,7 +23,7 @@ def test_reference_shape_tests_through_the_cpp_api():
     r = subprocess.run([_need("shape_api_test")], capture_output=True, text=True, timeout=120)
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "8 test(s), 0 failure(s)" in r.stdout
+    assert "5 test(s), 0 failure(s)" in r.stdout
 
 
 def test_host_program_matches_library_render_and_reference_ppm_format():
