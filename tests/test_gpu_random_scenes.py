@@ -62,3 +62,23 @@ def test_fast_equals_the_run_table_loop_on_random_scenes(torch, pt):
         assert torch.isfinite(ref).all(), trial
         assert torch.equal(fast, ref), (trial, n_shapes, cam, depth, (w, h, spp), int((fast != ref).any(dim=2).sum()))
     assert len(seen_kinds) >= 5          # short, mixed and general kind sets, with and without a hierarchy
+
+
+def test_unusual_viewports(torch, pt):
+    """The culling of camera rays works from the sample plane: a plane behind the camera (negative focal length: the
+    camera looks along +z), a mirrored viewport (negative height), a very wide and a very narrow view, a focal length
+    of zero (every ray direction degenerate) must all give the run-table loop's image."""
+    rng = np.random.default_rng(7)
+    sc = pt.Scene(*pt.parse_scene(random_scene(rng, 30, 0.3, True)))
+    front = pt.Scene(*pt.parse_scene("\n".join(MATERIALS + [
+        "plane light bounds -2 -2 2 2 rotate pi 0 1 0 translate 0 0 6", "sphere glass translate 0.3 0.2 3 scale 0.9",
+        "cube red translate -0.8 -0.4 2.5 scale 0.5 0.7 0.4", "sphere base translate 0 0 -3 scale 0.8"]) + "\n"))
+    for scene in (sc, front):
+        for focal, vph in ((-6.0, 5.0), (6.0, -5.0), (0.3, 5.0), (60.0, 5.0), (0.0, 5.0), (6.0, 1e-3), (-0.5, -40.0)):
+            imgs = []
+            for mode in (pt.PT_MATH_FAST, pt.PT_MATH_FAST_SCALAR):
+                cfg = pt.make_config(150, 90, 4, n_bounces=4, math_mode=mode, camera=(0.1, -0.2, 0.4))
+                cfg.focal_length, cfg.view_port_height = focal, vph
+                imgs.append(scene.render(cfg))
+            # (NaN == NaN is false: compare bit patterns, a degenerate view may legitimately produce NaNs in both)
+            assert torch.equal(imgs[0].view(torch.int32), imgs[1].view(torch.int32)), (focal, vph)
