@@ -1,5 +1,6 @@
 """A/B timing of two builds of the library on the 1080p frame, interleaved rounds in one process (development aid).
-    python tools/ab_time.py pathtracer_amd/libpt_hip.so pathtracer_amd/libpt_hip_exp.so"""
+    python tools/ab_time.py pathtracer_amd/libpt_hip.so pathtracer_amd/libpt_hip_exp.so
+AB_SCENE=synthetic|glassN (default: the default scene), AB_SPP, AB_DEPTH choose another frame."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,11 +11,13 @@ for path in sys.argv[1:]:
     L = C.CDLL(os.path.join(ROOT, path))
     for name in ("pt_scene_upload", "pt_render", "pt_scene_free"):
         getattr(L, name).argtypes = getattr(b.lib, name).argtypes
-    prims, n, mats, nm = b.default_scene()
+    scene_name = os.environ.get("AB_SCENE", "default")
+    prims, n, mats, nm = (b.synthetic_scene(5000, 4989, 12345) if scene_name == "synthetic" else
+                          (b.glass_grid_scene(int(scene_name[5:])) if scene_name.startswith("glass") else b.default_scene()))
     h = C.c_void_p()
     assert L.pt_scene_upload(prims, n, mats, nm, 0, C.byref(h)) == 0
     libs.append((path, L, h))
-cfg = b.make_config(1920, 1080, 64)
+cfg = b.make_config(1920, 1080, int(os.environ.get("AB_SPP", "64")), n_bounces=int(os.environ.get("AB_DEPTH", "5")))
 fb = torch.zeros((1080, 1920, 3), device="cuda")
 times = {p: [] for p, _, _ in libs}
 for rnd in range(12):
