@@ -193,3 +193,89 @@ def test_nearest_is_the_minimum_over_shapes(oracle):
     # facing normal and inside flag: inside means the geometric normal pointed along the ray
     hit = best_k >= 0
     assert ((near["nrm"][hit].astype(np.float64) * d[hit]).sum(1) <= 1e-6).all()
+
+
+# ---- the shading helpers against their textbook forms in float64 -------------------------------------------------
+# (written from the equations — Schlick's approximation, the mirror direction, Snell's law in vector form, the
+# uniform sphere parametrisation — not from the oracle's code; float32 inputs, float64 arithmetic)
+
+def test_shading_helpers_against_closed_forms(oracle):
+    ob = oracle
+    rng = np.random.default_rng(77)
+    n = 20000
+    unit = lambda v: v / np.linalg.norm(v, axis=1, keepdims=True)
+
+    # sampleHemisphere(u1, u2): the point of the unit sphere at height 2 u1 - 1 and azimuth 2 pi u2
+    u = rng.uniform(0.0, 1.0, (n, 2)).astype(np.float32)
+    u[0] = (1.0, 1.0); u[1] = (0.0, 0.0); u[2] = (0.5, 0.25)
+    got = ob.bsdf_batch(0, u).astype(np.float64)
+    z = 2.0 * u[:, 0].astype(np.float64) - 1.0
+    r = np.sqrt(np.maximum(0.0, 1.0 - z * z))
+    phi = 2.0 * np.pi * u[:, 1].astype(np.float64)
+    want = np.stack([r * np.cos(phi), r * np.sin(phi), z], axis=1)
+    assert np.abs(got - want).max() < 2e-6
+    assert np.abs(np.linalg.norm(got, axis=1) - 1.0).max() < 1e-6
+
+    # FresnelSchlick(n1, n2, cos): r0 + (1 - r0)(1 - cos)^5 with r0 = ((n1 - n2) / (n1 + n2))^2
+    x = np.stack([rng.uniform(1.0, 2.5, n), rng.uniform(1.0, 2.5, n), rng.uniform(0.0, 1.0, n)], axis=1).astype(np.float32)
+    got = ob.bsdf_batch(1, x)[:, 0].astype(np.float64)
+    n1, n2, c = (x[:, k].astype(np.float64) for k in range(3))
+    r0 = ((n1 - n2) / (n1 + n2)) ** 2
+    assert np.abs(got - (r0 + (1.0 - r0) * (1.0 - c) ** 5)).max() < 1e-6
+
+    # reflect(v, n) = v - 2 (v.n) n: the mirror image keeps the tangential part and flips the normal part
+    v = unit(rng.normal(size=(n, 3))).astype(np.float32)
+    nn = unit(rng.normal(size=(n, 3))).astype(np.float32)
+    got = ob.bsdf_batch(3, np.concatenate([v, nn], axis=1)).astype(np.float64)
+    v64, n64 = v.astype(np.float64), nn.astype(np.float64)
+    want = v64 - 2.0 * (v64 * n64).sum(axis=1, keepdims=True) * n64
+    assert np.abs(got - want).max() < 1e-6
+    assert np.abs((got * n64).sum(axis=1) + (v64 * n64).sum(axis=1)).max() < 1e-6
+
+    # refract(I, N, eta): Snell's law, eta sin(theta_i) = sin(theta_t); the zero vector beyond the critical angle
+    facing = (v64 * n64).sum(axis=1) < 0.0                       # N against I, as tracePath passes them
+    nf = np.where(facing[:, None], nn, -nn).astype(np.float32)
+    eta = rng.choice([1.0 / 1.5, 1.5, 1.0 / 1.3, 1.3], n).astype(np.float32)
+    got = ob.bsdf_batch(4, np.concatenate([v, nf, eta[:, None]], axis=1)).astype(np.float64)
+    cos_i = -(v64 * nf.astype(np.float64)).sum(axis=1)
+    sin2_t = eta.astype(np.float64) ** 2 * (1.0 - cos_i ** 2)
+    total = sin2_t > 1.0 + 1e-6
+    clear = sin2_t < 1.0 - 1e-6
+    assert total.sum() > 100 and clear.sum() > 1000
+    assert np.abs(got[total]).max() == 0.0
+    t = got[clear]
+    assert np.abs(np.linalg.norm(t, axis=1) - 1.0).max() < 1e-5                      # unit length for unit inputs
+    sin_t = np.linalg.norm(np.cross(t, nf[clear].astype(np.float64)), axis=1)
+    assert np.abs(sin_t - np.sqrt(sin2_t[clear])).max() < 1e-5                        # Snell
+    assert ((t * nf[clear].astype(np.float64)).sum(axis=1) < 0.0).all()               # through the surface
+    # coplanar with I and N
+    assert np.abs((np.cross(v64[clear], nf[clear].astype(np.float64)) * t).sum(axis=1)).max() < 1e-5
+
+    # getFresnelRatio(N, I, f0, f90, n1, n2): Schlick on the transmitted angle when leaving the denser medium, f90 under
+    # total internal reflection, blended between f0 and f90
+    f0 = rng.uniform(0.0, 0.2, n).astype(np.float32)
+    f90 = np.ones(n, np.float32)
+    n1 = rng.choice([1.0, 1.5, 1.3], n).astype(np.float32)
+    n2 = rng.choice([1.0, 1.5, 1.3], n).astype(np.float32)
+    got = ob.bsdf_batch(2, np.concatenate([nf, v, f0[:, None], f90[:, None], n1[:, None], n2[:, None]], axis=1))[:, 0].astype(np.float64)
+    cx = cos_i.copy()
+    ratio = n1.astype(np.float64) / n2.astype(np.float64)
+    s2 = ratio ** 2 * (1.0 - cx ** 2)
+    dense = n1 > n2
+    tir = dense & (s2 > 1.0 + 1e-6)
+    ok = ~(dense & (np.abs(s2 - 1.0) <= 1e-6))
+    cx = np.where(dense & ~tir, np.sqrt(np.maximum(0.0, 1.0 - s2)), cx)
+    r0 = ((n1.astype(np.float64) - n2) / (n1.astype(np.float64) + n2)) ** 2
+    fr = r0 + (1.0 - r0) * (1.0 - cx) ** 5
+    want = np.where(tir, f90, f0.astype(np.float64) * (1.0 - fr) + f90 * fr)
+    assert tir.sum() > 100
+    assert np.abs(got - want)[ok].max() < 2e-5
+
+    # lerp(a, b, t) = a (1 - t) + b t, and normalized(v)
+    a3, b3 = rng.normal(size=(n, 3)).astype(np.float32), rng.normal(size=(n, 3)).astype(np.float32)
+    tt = rng.uniform(0.0, 1.0, n).astype(np.float32)
+    got = ob.bsdf_batch(5, np.concatenate([a3, b3, tt[:, None]], axis=1)).astype(np.float64)
+    assert np.abs(got - (a3.astype(np.float64) * (1.0 - tt[:, None].astype(np.float64)) + b3.astype(np.float64) * tt[:, None].astype(np.float64))).max() < 1e-6
+    got = ob.bsdf_batch(6, a3).astype(np.float64)
+    assert np.abs(got - unit(a3.astype(np.float64))).max() < 1e-6
+    assert (ob.bsdf_batch(6, np.zeros((1, 3), np.float32)) == 0.0).all()              # the zero vector stays zero
