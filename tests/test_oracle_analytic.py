@@ -279,3 +279,40 @@ def test_shading_helpers_against_closed_forms(oracle):
     got = ob.bsdf_batch(6, a3).astype(np.float64)
     assert np.abs(got - unit(a3.astype(np.float64))).max() < 1e-6
     assert (ob.bsdf_batch(6, np.zeros((1, 3), np.float32)) == 0.0).all()              # the zero vector stays zero
+
+
+# ---- the whole tracePath estimator against a closed form: a furnace ----------------------------------------------
+FURNACE = "material furnace albedo 0.2 0.5 0.8 emissive 1 0.5 2\n" + "\n".join([
+    "plane furnace bounds -15 -15 15 15 rotate pi/2 1 0 0 translate 0 -2 0",
+    "plane furnace bounds -15 -15 15 15 rotate -pi/2 1 0 0 translate 0 2 0",
+    "plane furnace bounds -15 -15 15 15 rotate pi/2 0 1 0 translate -2 0 0",
+    "plane furnace bounds -15 -15 15 15 rotate -pi/2 0 1 0 translate 2 0 0",
+    "plane furnace bounds -15 -15 15 15 translate 0 0 -3",
+    "plane furnace bounds -15 -15 15 15 rotate pi 0 1 0 translate 0 0 3"]) + "\n"
+
+
+def furnace_expectation(n_bounces):
+    """Inside a closed room whose every wall has emission e and diffuse albedo a, a path adds coef * e at each hit
+    (bsdf.h:90-92), multiplies coef by a, survives the roulette with probability q = max(coef) and divides by q
+    (bsdf.h:155-164): whatever it hits next is the same wall material, so the expected radiance is
+    e * (1 + a + ... + a^n_bounces) per channel, independent of geometry and directions."""
+    a = np.array([0.2, 0.5, 0.8]); e = np.array([1.0, 0.5, 2.0])
+    return e * (1.0 - a ** (n_bounces + 1)) / (1.0 - a)
+
+
+def test_furnace_expectation_of_tracepath(oracle):
+    import ctypes as C
+    from pathtracer_amd import binding as b          # the scene parser is host code
+    ob = oracle
+    prims, n, mats, nm = b.parse_scene(FURNACE)
+    op = (ob.Prim * n).from_buffer_copy(bytes(prims)[: n * C.sizeof(ob.Prim)])
+    om = (ob.Material * nm).from_buffer_copy(bytes(mats)[: nm * C.sizeof(ob.Material)])
+    sc = ob.Scene(op, n, om, nm)
+    for depth in (0, 1, 5, 12):
+        img = sc.render(ob.make_config(96, 96, 64, n_bounces=depth)).astype(np.float64)
+        mean = img.mean(axis=(0, 1))
+        want = furnace_expectation(depth)
+        # 590 000 samples; a sample is e * (number of hits), at most (depth + 1) e / min(q): the mean is good to 1 %
+        assert np.abs(mean / want - 1.0).max() < 0.01, (depth, mean, want)
+    # depth 0: one hit, no randomness left in the value
+    assert np.abs(sc.render(ob.make_config(32, 32, 4, n_bounces=0)) - np.array([1.0, 0.5, 2.0], np.float32)).max() < 1e-6
