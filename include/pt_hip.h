@@ -108,6 +108,7 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
 /* The same with explicit build options (NULL = the defaults, which is what pt_scene_upload uses).  No counterpart
  * in the reference.  They change how PT_MATH_FAST searches the scene, never which hit it finds. */
 enum { PT_GENERAL_PLANES = 1, PT_GENERAL_CUBES = 2, PT_GENERAL_SPHERES = 4, PT_GENERAL_ALL = 7 };
+enum { PT_BVH_SPLIT_MEDIAN = 1, PT_BVH_SPLIT_AREA = 2 };
 typedef struct pt_upload_options {
     int32_t bvh_min_prims;  /* finite primitives (spheres, cubes, cylinders) from which PT_MATH_FAST builds a
                              * bounding-volume hierarchy; 0 = the default (96), values >= 2 */
@@ -115,6 +116,9 @@ typedef struct pt_upload_options {
     int32_t general_kinds;  /* PT_GENERAL_* bits: these shapes keep the general record kinds, tested in local space
                              * as shapes.h does, instead of the shorter world-space tests that axis-aligned planes,
                              * unrotated cubes and uniformly scaled spheres otherwise get */
+    int32_t bvh_split;      /* how the hierarchy divides a set of primitives: PT_BVH_SPLIT_MEDIAN = in halves along the
+                             * widest axis; PT_BVH_SPLIT_AREA + s (s = 0..5) = where the surface-area cost is least,
+                             * leaves at most s levels deeper than the even tree's; 0 = the default */
 } pt_upload_options;
 int pt_scene_upload_opt(const pt_prim* prims, int n_prims, const pt_material* mats, int n_mats, int device,
                         const pt_upload_options* opt, pt_scene** out);
@@ -124,13 +128,15 @@ int pt_scene_free(pt_scene* scene);
  * scene runs in another thread. */
 enum {
     PT_TUNE_TILE_LOG2 = 0,   /* log2 of the pixels per wave (2..6) when pt_config.tile_log2 is 0 */
-    PT_TUNE_WALK_BUDGET = 1, /* hierarchy nodes a lane visits per loop iteration (>= 1) */
+    PT_TUNE_WALK_BUDGET = 1, /* hierarchy nodes a lane visits (or takes off its stack) per loop iteration (>= 1) */
     PT_TUNE_SHADE_GATE = 2,  /* lanes whose hierarchy search is over before they are shaded together (1..64) */
     PT_TUNE_BVH_WALK = 3,    /* 1: walk the hierarchy in its skip-link form instead of the two-children-per-node form */
     PT_TUNE_GLASS_QUEUE = 4, /* PT_MATH_FAST, no hierarchy: entries per wave of the LDS queue in which hits on glass
                               * wait to be shaded together (8..64); -1: no queue, every hit is shaded where it is found */
     PT_TUNE_GLASS_GATE = 5,  /* queue entries from which free lanes take them back (1..queue size) */
-    PT_TUNE_COUNT = 6
+    PT_TUNE_LEAF_GATE = 6,   /* lanes holding a leaf of the hierarchy from which the wave stops descending and tests
+                              * them together (1..64; 64 = only when no lane can descend any further) */
+    PT_TUNE_COUNT = 7
 };
 int pt_scene_tune(pt_scene* scene, int knob, int value);
 int pt_scene_device(const pt_scene* scene);

@@ -44,11 +44,11 @@ class pt_config(C.Structure):
 
 
 class pt_upload_options(C.Structure):
-    _fields_ = [("bvh_min_prims", C.c_int32), ("bvh_leaf_prims", C.c_int32), ("general_kinds", C.c_int32)]
+    _fields_ = [("bvh_min_prims", C.c_int32), ("bvh_leaf_prims", C.c_int32), ("general_kinds", C.c_int32), ("bvh_split", C.c_int32)]
 
 
 PT_GENERAL_PLANES, PT_GENERAL_CUBES, PT_GENERAL_SPHERES, PT_GENERAL_ALL = 1, 2, 4, 7
-PT_TUNE_TILE_LOG2, PT_TUNE_WALK_BUDGET, PT_TUNE_SHADE_GATE, PT_TUNE_BVH_WALK, PT_TUNE_GLASS_QUEUE, PT_TUNE_GLASS_GATE = range(6)
+PT_TUNE_TILE_LOG2, PT_TUNE_WALK_BUDGET, PT_TUNE_SHADE_GATE, PT_TUNE_BVH_WALK, PT_TUNE_GLASS_QUEUE, PT_TUNE_GLASS_GATE, PT_TUNE_LEAF_GATE = range(7)
 
 
 class PtError(RuntimeError):
@@ -239,12 +239,12 @@ def _ptr(t):
 class Scene:
     """Device copy of a scene (pt_scene_upload / pt_scene_free)."""
 
-    def __init__(self, prims, n, mats, n_mats, device=0, bvh_min_prims=0, bvh_leaf_prims=0, general_kinds=False):
+    def __init__(self, prims, n, mats, n_mats, device=0, bvh_min_prims=0, bvh_leaf_prims=0, general_kinds=False, bvh_split=0):
         """The keyword options are pt_upload_options (0 / False = the library's defaults)."""
         self.n, self.n_mats, self.device = n, n_mats, device
         h = C.c_void_p(0)
-        if bvh_min_prims or bvh_leaf_prims or general_kinds:
-            opt = pt_upload_options(bvh_min_prims, bvh_leaf_prims, PT_GENERAL_ALL if general_kinds is True else int(general_kinds))
+        if bvh_min_prims or bvh_leaf_prims or general_kinds or bvh_split:
+            opt = pt_upload_options(bvh_min_prims, bvh_leaf_prims, PT_GENERAL_ALL if general_kinds is True else int(general_kinds), bvh_split)
             _check(lib.pt_scene_upload_opt(prims, n, mats, n_mats, device, C.byref(opt), C.byref(h)))
         else:
             _check(lib.pt_scene_upload(prims, n, mats, n_mats, device, C.byref(h)))

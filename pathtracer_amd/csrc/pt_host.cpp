@@ -371,10 +371,29 @@ void pack_sorted(const std::vector<Baked>& baked, const std::vector<int>& ids, s
     std::memcpy(&data[FP_KINDS], hdr.count, sizeof(hdr.count));
 }
 
-// Median-split hierarchy over ids[lo, hi), appended to `nodes` in depth-first order.  Boxes are padded so that
-// the rounding of the kernels' slab test can never cull a primitive its own test would accept.
-void build_bvh(const std::vector<Baked>& baked, std::vector<int>& ids, int lo, int hi, std::vector<BNode>& nodes,
-               std::vector<BPrim>& bprims, int leaf_prims) {
+// Hierarchy over ids[lo, hi), appended to `nodes` in depth-first order.  Boxes are padded so that the rounding of
+// the kernels' slab test can never cull a primitive its own test would accept.
+// `levels` is the depth the leaves below this node may reach (hi - lo <= leaf_prims << levels).  With `sah` the
+// split is the one of least surface-area cost (area(left) * count(left) + area(right) * count(right)) over the three
+// axes and every position of the centroid order that keeps both sides within levels - 1; without it, the median
+// of the widest centroid axis.
+struct BvhBuild {
+    const std::vector<Baked>& baked;
+    std::vector<BNode>& nodes;
+    std::vector<BPrim>& bprims;
+    int leaf_prims;
+    bool sah;
+    std::vector<float> suffix;   // scratch: area of the box of the sorted range's tail
+};
+
+float box_area(const float* lo, const float* hi) {
+    const float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+    return x * y + y * z + z * x;
+}
+
+void build_bvh(BvhBuild& B, std::vector<int>& ids, int lo, int hi, int levels) {
+    const std::vector<Baked>& baked = B.baked;
+    std::vector<BNode>& nodes = B.nodes;
     const size_t me = nodes.size();
     nodes.push_back(BNode());
     float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -391,8 +410,9 @@ void build_bvh(const std::vector<Baked>& baked, std::vector<int>& ids, int lo, i
         const float pad = 1e-4f * (1.0f + fmaxf(fabsf(blo[a]), fabsf(bhi[a])));
         nodes[me].lo[a] = blo[a] - pad; nodes[me].hi[a] = bhi[a] + pad;
     }
-    if (hi - lo <= leaf_prims) {
-        nodes[me].leaf = (int32_t)((bprims.size() << 4) | (size_t)(hi - lo));
+    const int n = hi - lo;
+    if (n <= B.leaf_prims) {
+        nodes[me].leaf = (int32_t)((B.bprims.size() << 4) | (size_t)n);
         std::sort(ids.begin() + lo, ids.begin() + hi);
         for (int i = lo; i < hi; i++) {
             const Baked& b = baked[ids[i]];
@@ -400,21 +420,59 @@ void build_bvh(const std::vector<Baked>& baked, std::vector<int>& ids, int lo, i
             std::memset(&q, 0, sizeof(q));
             std::memcpy(q.rec, b.rec, 12 * sizeof(float));
             q.kind = b.kind; q.id = ids[i] << 3;
-            bprims.push_back(q);
+            B.bprims.push_back(q);
         }
     } else {
+        auto by_centroid = [&](int axis) {
+            return [&baked, axis](int x, int y) {
+                const float cx = baked[x].lo[axis] + baked[x].hi[axis], cy = baked[y].lo[axis] + baked[y].hi[axis];
+                return cx < cy || (cx == cy && x < y);
+            };
+        };
         int axis = 0;
         for (int a = 1; a < 3; a++) if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
-        const int mid = (lo + hi) / 2;
-        std::nth_element(ids.begin() + lo, ids.begin() + mid, ids.begin() + hi, [&](int x, int y) {
-            const float cx = baked[x].lo[axis] + baked[x].hi[axis], cy = baked[y].lo[axis] + baked[y].hi[axis];
-            return cx < cy || (cx == cy && x < y);
-        });
+        int mid = (lo + hi) / 2;
+        // each side may hold at most `cap` primitives if its leaves are to stay within levels - 1
+        const long long cap = levels >= 1 ? (long long)B.leaf_prims << std::min(levels - 1, 40) : 1;
+        const int k_min = (int)std::max<long long>(1, n - cap), k_max = (int)std::min<long long>(n - 1, cap);
+        if (B.sah && k_min < k_max) {
+            float best_cost = INFINITY;
+            int best_axis = axis, best_k = mid - lo;
+            B.suffix.resize((size_t)n + 1);
+            for (int a = 0; a < 3; a++) {
+                std::sort(ids.begin() + lo, ids.begin() + hi, by_centroid(a));
+                float l[3] = {INFINITY, INFINITY, INFINITY}, h[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (int i = n - 1; i >= 1; i--) {
+                    const Baked& b = baked[ids[lo + i]];
+                    for (int c = 0; c < 3; c++) { l[c] = fminf(l[c], b.lo[c]); h[c] = fmaxf(h[c], b.hi[c]); }
+                    B.suffix[(size_t)i] = box_area(l, h);
+                }
+                for (int c = 0; c < 3; c++) { l[c] = INFINITY; h[c] = -INFINITY; }
+                for (int k = 1; k <= k_max; k++) {        // k primitives on the left
+                    const Baked& b = baked[ids[lo + k - 1]];
+                    for (int c = 0; c < 3; c++) { l[c] = fminf(l[c], b.lo[c]); h[c] = fmaxf(h[c], b.hi[c]); }
+                    if (k < k_min) continue;
+                    const float cost = box_area(l, h) * (float)k + B.suffix[(size_t)k] * (float)(n - k);
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_k = k; }
+                }
+            }
+            axis = best_axis; mid = lo + best_k;
+            if (axis != 2) std::sort(ids.begin() + lo, ids.begin() + hi, by_centroid(axis));
+        } else {
+            std::nth_element(ids.begin() + lo, ids.begin() + mid, ids.begin() + hi, by_centroid(axis));
+        }
         nodes[me].leaf = -1;
-        build_bvh(baked, ids, lo, mid, nodes, bprims, leaf_prims);
-        build_bvh(baked, ids, mid, hi, nodes, bprims, leaf_prims);
+        build_bvh(B, ids, lo, mid, levels - 1);
+        build_bvh(B, ids, mid, hi, levels - 1);
     }
     nodes[me].skip = (int32_t)nodes.size();
+}
+
+// Levels a tree over n primitives needs when every split is as even as it can be.
+int bvh_min_levels(int n, int leaf_prims) {
+    int levels = 0;
+    while (((long long)leaf_prims << levels) < n) levels++;
+    return levels;
 }
 
 // The fat form of a skip-link tree whose leaves hold one primitive each: one entry per inner node, in the same
@@ -535,8 +593,9 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
 int pt_scene_upload_opt(const pt_prim* prims, int n_prims, const pt_material* mats, int n_mats, int device,
                         const pt_upload_options* opt, pt_scene** out) {
     if (!prims || !mats || !out || n_prims <= 0 || n_mats <= 0) return PT_FAIL("pt_scene_upload: bad arguments");
-    pt_upload_options o = {0, 0, 0};
+    pt_upload_options o = {};
     if (opt) o = *opt;
+    if (o.bvh_split < 0 || o.bvh_split > PT_BVH_SPLIT_AREA + 5) return PT_FAIL("pt_scene_upload_opt: bvh_split must be 0..PT_BVH_SPLIT_AREA + 5");
     if (o.bvh_min_prims != 0 && o.bvh_min_prims < 2) return PT_FAIL("pt_scene_upload_opt: bvh_min_prims must be 0 or >= 2");
     if (o.bvh_leaf_prims < 0 || o.bvh_leaf_prims > 15) return PT_FAIL("pt_scene_upload_opt: bvh_leaf_prims must be 0..15");
     for (int k = 0; k < n_prims; k++) {
@@ -586,10 +645,13 @@ int pt_scene_upload_opt(const pt_prim* prims, int n_prims, const pt_material* ma
     const int bvh_min = o.bvh_min_prims ? o.bvh_min_prims : BVH_MIN_PRIMS;
     if ((int)finite.size() >= bvh_min) {
         const int leaf_prims = o.bvh_leaf_prims ? o.bvh_leaf_prims : BVH_LEAF_PRIMS;
-        build_bvh(baked, finite, 0, (int)finite.size(), bnodes, bprims, leaf_prims);
+        const int split = o.bvh_split ? o.bvh_split : BVH_SPLIT;
+        BvhBuild build = {baked, bnodes, bprims, leaf_prims, split >= PT_BVH_SPLIT_AREA, {}};
+        const int slack = split >= PT_BVH_SPLIT_AREA ? split - PT_BVH_SPLIT_AREA : 0;
+        build_bvh(build, finite, 0, (int)finite.size(), bvh_min_levels((int)finite.size(), leaf_prims) + slack);
         if (leaf_prims == 1 && finite.size() >= 2 && (int)finite.size() <= BFAT_MAX_PRIMS) {
             fat_depth = build_fat(bnodes, bfat);
-            if (fat_depth > WALK_STACK_MAX) bfat.clear();   // cannot happen for a median split over <= 2^19 leaves
+            if (fat_depth > WALK_STACK_MAX) bfat.clear();   // cannot happen: the builder keeps <= 2^19 leaves within 19 + 5 levels
         }
         if (top.empty()) {   // the loop over the other primitives still wants one (empty) chunk to read
             fdata_top.assign(FDATA_CHUNK + 16, 0.0f);
@@ -675,6 +737,7 @@ int pt_scene_tune(pt_scene* sc, int knob, int value) {
         case PT_TUNE_BVH_WALK: ok = ok || value == 1; break;
         case PT_TUNE_GLASS_QUEUE: ok = ok || value == -1 || (value >= 8 && value <= 64); break;
         case PT_TUNE_GLASS_GATE: ok = ok || (value >= 1 && value <= 64); break;
+        case PT_TUNE_LEAF_GATE: ok = ok || (value >= 1 && value <= 64); break;
     }
     if (!ok) return PT_FAIL("pt_scene_tune: value out of range for this knob");
     sc->tune[knob] = value;
@@ -759,7 +822,8 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
         a.sorted = sc->sorted_top;
         // measured optimum on the 10 000-primitive scene is flat around these (a visit of the fat form decides
         // about two boxes, so its budget is half the skip-link form's)
-        a.walk_budget = a.bfat ? 16 : 32; a.shade_gate = 8;
+        a.walk_budget = a.bfat ? 16 : 32; a.shade_gate = 8; a.leaf_gate = 8;
+        if (sc->tune[PT_TUNE_LEAF_GATE] != 0) a.leaf_gate = sc->tune[PT_TUNE_LEAF_GATE];
         if (sc->tune[PT_TUNE_WALK_BUDGET] != 0) a.walk_budget = sc->tune[PT_TUNE_WALK_BUDGET];
         if (sc->tune[PT_TUNE_SHADE_GATE] != 0) a.shade_gate = sc->tune[PT_TUNE_SHADE_GATE];
     } else if (batched) {

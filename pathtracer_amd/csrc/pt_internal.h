@@ -114,10 +114,13 @@ struct BFat {
     float hi_b[3]; int32_t pad1;
 };
 constexpr int BFAT_MAX_PRIMS = 1 << 19;
-constexpr int WALK_STACK_MAX = 24;    // stack entries per lane: a median-split tree over 2^19 leaves is 19 levels deep
+constexpr int WALK_STACK_MAX = 24;    // stack entries per lane: the builder keeps 2^19 leaves within 19 + 5 levels
 constexpr int WALK_NONE = 0x7fffffff; // "no node in hand": the next one comes off the stack
-constexpr int BVH_MIN_PRIMS = 96;    // fewer finite primitives than this: no hierarchy, the loop tests them all (measured
-                                     // crossover: ~60 tiny scattered shapes, above 65 large glass spheres at depth 31)
+constexpr int BVH_MIN_PRIMS = 60;    // fewer finite primitives than this: no hierarchy, the loop tests them all (measured
+                                     // at 1080p: 48 small scattered shapes 3.06 ms through the hierarchy, 2.43 through the
+                                     // loop; 64: 3.24 vs 3.92; 8x8 large glass spheres at depth 31: 3.55 vs 4.09)
+constexpr int BVH_SPLIT = 4;          // PT_BVH_SPLIT_AREA + 2: 10 000 small shapes 18.35 ms (median split 20.66, + 0: 18.93,
+                                      // + 3: 18.36), 10x10 large glass spheres at depth 31 3.87 ms (5.44, 4.45, 3.87)
 constexpr int BVH_LEAF_PRIMS = 1;     // measured on the 10 000-primitive scene: 1 is fastest (24.4 ms), 4: 27.7, 8: 29.5
 
 
@@ -186,6 +189,7 @@ struct RenderArgs {
     int32_t n_bnodes;
     int32_t walk_budget;                   // hierarchy nodes a lane visits per loop iteration
     int32_t shade_gate;                    // lanes whose search is over before they are shaded together
+    int32_t leaf_gate;                     // lanes holding a leaf before the wave leaves the node loop to test them
     // PT_MATH_FAST without a hierarchy: hits that need the full shading (glass, paths inside a shape) are set aside
     // in a per-wave queue in LDS and shaded together.  q_cap = 0: the plain loop.
     int32_t q_cap;                         // queue entries per wave (64 bytes each)

@@ -49,6 +49,16 @@ struct PhaseClock { __device__ void start() {} __device__ void mark(int) {} __de
 #define PHASE(clk, i) do { } while (0)
 #endif
 
+#ifdef PT_WALK_CENSUS
+// Development aid: where the lanes of a wave are during the hierarchy walk.  [0] trips of the node loop, then lanes
+// summed over those trips: [1] visiting a node, [2] holding a leaf, [3] finished, [4] about to pop, [5] in the wave;
+// [6] leaf phases, [7] lanes testing a leaf in them.  Not compiled into libpt_hip.so.
+__device__ unsigned long long g_walk_census[8];
+#define CENSUS(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if (__builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0u)) == 0u) atomicAdd(&g_walk_census[i], v_); } while (0)
+#else
+#define CENSUS(i, v) do { } while (0)
+#endif
+
 namespace ptf {
 
 struct V3 { float x, y, z; };
@@ -480,8 +490,11 @@ PTD void walk_hierarchy(V3 o, V3 d, float dd, float idd, const BNode* __restrict
 // the reference in hand (WALK_NONE: take the next one off the stack), `sp` the stack height; the search is over
 // when cur == WALK_NONE and sp == 0.  Same result as walk_hierarchy: the order of the visits does not matter to
 // the (distance, scene index) rule the leaves apply.
+// The control flow is the wave's, not the lane's: every trip of the node loop is, for each lane, an optional pop
+// followed by an optional visit, and the wave leaves the loop when no lane can go on, when `leaf_gate` lanes hold a
+// leaf, or after `budget` trips; then the lanes that hold a leaf test it together, its whole record fetched at once.
 PTD void walk_fat(V3 o, V3 d, float dd, float idd, const BFat* __restrict__ fat, const BPrim* __restrict__ prims,
-                  Best& b, int& cur, int& sp, uint32_t* stack, int budget) {
+                  Best& b, int& cur, int& sp, uint32_t* stack, int budget, int leaf_gate) {
     // 1/d kept finite (+-1e30): with an infinite reciprocal, plane*inv - o*inv is inf - inf = NaN for every box on the
     // origin's side of an axis the ray does not move along, v_min/v_max drop the NaN, and that axis never culls — the
     // walk stays correct but an axis-parallel ray would descend most of the tree
@@ -489,54 +502,62 @@ PTD void walk_fat(V3 o, V3 d, float dd, float idd, const BFat* __restrict__ fat,
                       __builtin_amdgcn_fmed3f(rcp(d.z), -1e30f, 1e30f));
     const V3 noi = v3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
     for (;;) {
-        while (budget > 0) {
-            if (cur == WALK_NONE) {
-                if (sp == 0) break;
+        for (; budget > 0; budget--) {
+            budget = __builtin_amdgcn_readfirstlane(budget);
+            if (cur == WALK_NONE && sp != 0) {
                 const uint32_t e = stack[(--sp) * 64];
-                if (__uint_as_float(e & 0xFFF00000u) > b.t) continue;
-                cur = (e & 0x80000u) ? ~(int)(e & 0x7FFFFu) : (int)(e & 0x7FFFFu);
+                const int ref = (e & 0x80000u) ? ~(int)(e & 0x7FFFFu) : (int)(e & 0x7FFFFu);
+                cur = __uint_as_float(e & 0xFFF00000u) > b.t ? WALK_NONE : ref;
             }
-            if (cur < 0) break;                     // a leaf: test it below, together with the other lanes' leaves
-            budget--;
-            const float4* N = reinterpret_cast<const float4*>(fat + cur);
-            const float4 A0 = N[0], A1 = N[1], B0 = N[2], B1 = N[3];
-            // slab tests of both boxes as plane*inv - o*inv (inv is finite, see above; an origin exactly on a plane of
-            // an axis the ray does not move along gives 0 * 1e30 = 0: inside that slab)
-            const float a0x = __builtin_fmaf(A0.x, inv.x, noi.x), a1x = __builtin_fmaf(A1.x, inv.x, noi.x);
-            const float a0y = __builtin_fmaf(A0.y, inv.y, noi.y), a1y = __builtin_fmaf(A1.y, inv.y, noi.y);
-            const float a0z = __builtin_fmaf(A0.z, inv.z, noi.z), a1z = __builtin_fmaf(A1.z, inv.z, noi.z);
-            const float b0x = __builtin_fmaf(B0.x, inv.x, noi.x), b1x = __builtin_fmaf(B1.x, inv.x, noi.x);
-            const float b0y = __builtin_fmaf(B0.y, inv.y, noi.y), b1y = __builtin_fmaf(B1.y, inv.y, noi.y);
-            const float b0z = __builtin_fmaf(B0.z, inv.z, noi.z), b1z = __builtin_fmaf(B1.z, inv.z, noi.z);
-            const float tna = max3(__builtin_fminf(a0x, a1x), __builtin_fminf(a0y, a1y), __builtin_fmaxf(__builtin_fminf(a0z, a1z), 0.0f));
-            const float tfa = min3(__builtin_fmaxf(a0x, a1x), __builtin_fmaxf(a0y, a1y), __builtin_fminf(__builtin_fmaxf(a0z, a1z), b.t));
-            const float tnb = max3(__builtin_fminf(b0x, b1x), __builtin_fminf(b0y, b1y), __builtin_fmaxf(__builtin_fminf(b0z, b1z), 0.0f));
-            const float tfb = min3(__builtin_fmaxf(b0x, b1x), __builtin_fmaxf(b0y, b1y), __builtin_fminf(__builtin_fmaxf(b0z, b1z), b.t));
-            const bool ha = tna <= tfa, hb = tnb <= tfb;
-            const int ra = __float_as_int(A0.w), rb = __float_as_int(A1.w);
-            if (ha && hb) {
+            const bool inner = (uint32_t)cur < (uint32_t)WALK_NONE;
+            const bool pending = cur == WALK_NONE && sp != 0;
+            if (__ballot(inner || pending) == 0ull || __popcll(__ballot(cur < 0)) >= leaf_gate) break;
+            CENSUS(0, 1); CENSUS(1, __popcll(__ballot(inner))); CENSUS(2, __popcll(__ballot(cur < 0)));
+            CENSUS(3, __popcll(__ballot(cur == WALK_NONE && sp == 0))); CENSUS(4, __popcll(__ballot(pending))); CENSUS(5, __popcll(__ballot(true)));
+            if (inner) {
+                const float4* N = reinterpret_cast<const float4*>(fat + cur);
+                const float4 A0 = N[0], A1 = N[1], B0 = N[2], B1 = N[3];
+                // slab tests of both boxes as plane*inv - o*inv (inv is finite, see above; an origin exactly on a plane
+                // of an axis the ray does not move along gives 0 * 1e30 = 0: inside that slab)
+                const float a0x = __builtin_fmaf(A0.x, inv.x, noi.x), a1x = __builtin_fmaf(A1.x, inv.x, noi.x);
+                const float a0y = __builtin_fmaf(A0.y, inv.y, noi.y), a1y = __builtin_fmaf(A1.y, inv.y, noi.y);
+                const float a0z = __builtin_fmaf(A0.z, inv.z, noi.z), a1z = __builtin_fmaf(A1.z, inv.z, noi.z);
+                const float b0x = __builtin_fmaf(B0.x, inv.x, noi.x), b1x = __builtin_fmaf(B1.x, inv.x, noi.x);
+                const float b0y = __builtin_fmaf(B0.y, inv.y, noi.y), b1y = __builtin_fmaf(B1.y, inv.y, noi.y);
+                const float b0z = __builtin_fmaf(B0.z, inv.z, noi.z), b1z = __builtin_fmaf(B1.z, inv.z, noi.z);
+                const float tna = max3(__builtin_fminf(a0x, a1x), __builtin_fminf(a0y, a1y), __builtin_fmaxf(__builtin_fminf(a0z, a1z), 0.0f));
+                const float tfa = min3(__builtin_fmaxf(a0x, a1x), __builtin_fmaxf(a0y, a1y), __builtin_fminf(__builtin_fmaxf(a0z, a1z), b.t));
+                const float tnb = max3(__builtin_fminf(b0x, b1x), __builtin_fminf(b0y, b1y), __builtin_fmaxf(__builtin_fminf(b0z, b1z), 0.0f));
+                const float tfb = min3(__builtin_fmaxf(b0x, b1x), __builtin_fmaxf(b0y, b1y), __builtin_fminf(__builtin_fmaxf(b0z, b1z), b.t));
+                const bool ha = tna <= tfa, hb = tnb <= tfb;
+                const int ra = __float_as_int(A0.w), rb = __float_as_int(A1.w);
                 const bool a_first = tna <= tnb;
-                const int far = a_first ? rb : ra;
+                const int far = a_first ? rb : ra, near = a_first ? ra : rb;
                 const float tfar = a_first ? tnb : tna;
-                const uint32_t packed = far < 0 ? (0x80000u | (uint32_t)~far) : (uint32_t)far;
-                stack[sp * 64] = (__float_as_uint(tfar) & 0xFFF00000u) | packed;
-                sp++;
-                cur = a_first ? ra : rb;
-            } else {
-                cur = ha ? ra : (hb ? rb : WALK_NONE);
+                if (ha & hb) {
+                    const uint32_t packed = far < 0 ? (0x80000u | (uint32_t)~far) : (uint32_t)far;
+                    stack[sp * 64] = (__float_as_uint(tfar) & 0xFFF00000u) | packed;
+                    sp++;
+                }
+                cur = (ha & hb) ? near : (ha ? ra : (hb ? rb : WALK_NONE));
             }
         }
-        if (cur >= 0) break;                        // nothing in hand (finished) or an inner node and no budget left
-        const BPrim* q = prims + ~cur;
-        cur = WALK_NONE;
-        const float* R = q->rec;
-        const int id = q->id;
-        switch (q->kind) {
-            case FP_SPHERE_WS: test_sphere_ws(R, o, d, dd, idd, id, b); break;
-            case FP_CUBE: test_cube(R, o, d, id, b); break;
-            case FP_CUBE_AA: test_cube_box(R, o, inv, id, b); break;
-            case FP_SPHERE: test_sphere(R, o, d, id, b); break;
-            default: test_cylinder(R, o, d, id, b); break;
+        const bool leaf = cur < 0;
+        if (__ballot(leaf) == 0ull) break;            // out of trips, or every lane's search is over
+        CENSUS(6, 1); CENSUS(7, __popcll(__ballot(leaf)));
+        if (leaf) {
+            const float4* Q = reinterpret_cast<const float4*>(prims + ~cur);
+            const float4 q0 = Q[0], q1 = Q[1], q2 = Q[2], q3 = Q[3];
+            const float R[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+            const int id = __float_as_int(q3.y);
+            cur = WALK_NONE;
+            switch (__float_as_int(q3.x)) {
+                case FP_SPHERE_WS: test_sphere_ws(R, o, d, dd, idd, id, b); break;
+                case FP_CUBE: test_cube(R, o, d, id, b); break;
+                case FP_CUBE_AA: test_cube_box(R, o, inv, id, b); break;
+                case FP_SPHERE: test_sphere(R, o, d, id, b); break;
+                default: test_cylinder(R, o, d, id, b); break;
+            }
         }
     }
 }
@@ -849,7 +870,7 @@ struct WalkPath : Path {
 // the shading code does not run for one or two lanes at a time.
 template <bool FAT>
 PTD bool path_step_walk(WalkPath& p, const SceneRefs& sc, const FShade* shade, const DMat* mats, int n_bounces,
-                        int bsdf_model, int walk_budget, int shade_gate, uint32_t* stack, PhaseClock& clk) {
+                        int bsdf_model, int walk_budget, int shade_gate, int leaf_gate, uint32_t* stack, PhaseClock& clk) {
     const float dd = dot(p.d, p.d), idd = rcp(dd);
     if (p.node < 0) {
         p.best = best_none();
@@ -860,7 +881,7 @@ PTD bool path_step_walk(WalkPath& p, const SceneRefs& sc, const FShade* shade, c
     PHASE(clk, 7);
     bool done;
     if (FAT) {
-        walk_fat(p.o, p.d, dd, idd, sc.fat, sc.bprims, p.best, p.node, p.sp, stack, walk_budget);
+        walk_fat(p.o, p.d, dd, idd, sc.fat, sc.bprims, p.best, p.node, p.sp, stack, walk_budget, leaf_gate);
         done = p.node == WALK_NONE && p.sp == 0;
     } else {
         walk_hierarchy(p.o, p.d, dd, idd, sc.nodes, sc.n_nodes, sc.bprims, p.best, p.node, walk_budget);
@@ -954,7 +975,7 @@ struct FastTracer {
         return path_step<false, SORTED, KM>(p, sc, c.shade, c.mats, a.n_bounces, a.bsdf_model, c.clk);
     }
     static PTD bool step_path(ptf::WalkPath& p, const SceneRefs& sc, const RenderArgs& a, FastCtx& c) {
-        return path_step_walk<BVH == 2>(p, sc, c.shade, c.mats, a.n_bounces, a.bsdf_model, a.walk_budget, a.shade_gate, c.wstack, c.clk);
+        return path_step_walk<BVH == 2>(p, sc, c.shade, c.mats, a.n_bounces, a.bsdf_model, a.walk_budget, a.shade_gate, a.leaf_gate, c.wstack, c.clk);
     }
     static PTD void idle(Path& p) {
         p.o = v3(0.0f, 0.0f, 0.0f); p.d = v3(0.0f, 0.0f, 0.0f);
@@ -1524,6 +1545,15 @@ extern "C" int pt_dev_phase_cycles(unsigned long long* out, int reset) {
     PT_CHECK(hipDeviceSynchronize());
     PT_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 24 * sizeof(unsigned long long)));
     if (reset) { unsigned long long z[24] = {0}; PT_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z))); }
+    return 0;
+}
+#endif
+
+#ifdef PT_WALK_CENSUS
+extern "C" int pt_dev_walk_census(unsigned long long* out, int reset) {
+    PT_CHECK(hipDeviceSynchronize());
+    PT_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_census), 8 * sizeof(unsigned long long)));
+    if (reset) { unsigned long long z[8] = {0}; PT_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_walk_census), z, sizeof(z))); }
     return 0;
 }
 #endif

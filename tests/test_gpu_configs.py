@@ -179,8 +179,8 @@ def test_more_materials_and_primitives_than_the_lds_tables_hold(oracle):
         lines.append("%s m%d translate %.4f %.4f %.4f scale %.4f" % (("sphere", "cube")[k % 2], k % 40, pos[0], pos[1], pos[2], rng.uniform(0.05, 0.2)))
     prims, n, mats, nm = pt.parse_scene("\n".join(lines) + "\n")
     assert nm == 41 and n == 73
-    sc = pt.Scene(prims, n, mats, nm)
-    assert sc.bvh_nodes == 0                       # 70 finite primitives: below the hierarchy's threshold
+    sc = pt.Scene(prims, n, mats, nm, bvh_min_prims=1000000)      # the loop over all primitives, not the hierarchy
+    assert sc.bvh_nodes == 0
     w, h, spp = 160, 90, 8
     a = sc.render(pt.make_config(w, h, spp, math_mode=pt.PT_MATH_FAST))
     b = sc.render(pt.make_config(w, h, spp, math_mode=pt.PT_MATH_FAST_LDS))

@@ -1,5 +1,5 @@
 """Where the hierarchy overtakes the loop over all primitives: small scattered shapes and grids of large glass spheres
-(development aid; PT_BVH_MIN is read at upload)."""
+(development aid)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,4 +1,4 @@
-"""Walk budget / shade gate sweep on the 10 000-primitive scene (development aid)."""
+"""Walk budget / shade gate / leaf gate sweep on the 10 000-primitive scene, 1080p@16 (development aid)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,11 +14,13 @@ def timed():
         e0.record(); sc.render(cfg, out=out); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     return min(ts)
-for walk in ("fat", "skip"):
+for walk, leaf_gates in (("fat", (8, 16)), ("skip", (0,))):
     sc.tune(pt.binding.PT_TUNE_BVH_WALK, 1 if walk == "skip" else 0)
-    for budget in (4, 8, 16, 32, 64, 1000000):
-        row = []
-        for gate in (1, 8, 16, 32, 64):
-            sc.tune(pt.binding.PT_TUNE_WALK_BUDGET, budget).tune(pt.binding.PT_TUNE_SHADE_GATE, gate)
-            row.append("%.2f" % timed())
-        print(walk, "budget", budget, "gate 1/8/16/32/64:", " ".join(row), flush=True)
+    for leaf_gate in leaf_gates:
+        sc.tune(pt.binding.PT_TUNE_LEAF_GATE, leaf_gate)
+        for budget in (16, 32, 64, 128, 1000000):
+            row = []
+            for gate in (4, 8, 12, 16, 24, 32):
+                sc.tune(pt.binding.PT_TUNE_WALK_BUDGET, budget).tune(pt.binding.PT_TUNE_SHADE_GATE, gate)
+                row.append("%.2f" % timed())
+            print(walk, "leaf gate", leaf_gate, "budget", budget, "shade gate 4/8/12/16/24/32:", " ".join(row), flush=True)
