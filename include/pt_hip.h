@@ -51,7 +51,7 @@ typedef struct pt_prim {
 enum {
     PT_MATH_PARITY = 0, /* reference operation order, IEEE div/sqrt, no FMA contraction */
     PT_MATH_FAST = 1,   /* same algorithm, FMA + v_rcp/v_rsq/v_sin/v_cos, restructured tests; scenes with
-                         * 96 or more finite primitives are searched through a bounding-volume hierarchy
+                         * 60 or more finite primitives are searched through a bounding-volume hierarchy
                          * (same nearest hit as the loop of shapes.h:82-98, lowest index on ties) */
     /* The loop over ALL primitives, in its two forms (same results bit for bit): */
     PT_MATH_FAST_SCALAR = 2, /* primitive records fetched by scalar loads */
@@ -111,7 +111,7 @@ enum { PT_GENERAL_PLANES = 1, PT_GENERAL_CUBES = 2, PT_GENERAL_SPHERES = 4, PT_G
 enum { PT_BVH_SPLIT_MEDIAN = 1, PT_BVH_SPLIT_AREA = 2 };
 typedef struct pt_upload_options {
     int32_t bvh_min_prims;  /* finite primitives (spheres, cubes, cylinders) from which PT_MATH_FAST builds a
-                             * bounding-volume hierarchy; 0 = the default (96), values >= 2 */
+                             * bounding-volume hierarchy; 0 = the default (60), values >= 2 */
     int32_t bvh_leaf_prims; /* primitives per leaf, 1..15; 0 = the default (1) */
     int32_t general_kinds;  /* PT_GENERAL_* bits: these shapes keep the general record kinds, tested in local space
                              * as shapes.h does, instead of the shorter world-space tests that axis-aligned planes,

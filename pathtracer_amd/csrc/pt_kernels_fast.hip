@@ -907,7 +907,8 @@ constexpr int LDS_MAX_MATS = 32;
 struct FastCtx {
     const FShade* shade;   // LDS or global
     const DMat* mats;      // LDS or global
-    float* pxt;            // LDS, this wave's [3][64]: i-0.5, H-j-0.5, K_px bits
+    float* pxt;            // LDS, this wave's [3][pxs]: i-0.5, H-j-0.5, K_px bits
+    uint32_t pxs;          // pixels each of the three rows has room for
     float* stage;          // LDS, FDATA_CHUNK floats shared by the workgroup (LDS-tiled kernel only)
     uint32_t* wstack;      // LDS, this lane's column of the wave's walk stack (fat hierarchy only)
     PhaseClock clk;
@@ -924,15 +925,15 @@ struct FastTracer {
     // (main.cu:62) and the pixel's RNG key.
     static PTD void prologue(const RenderArgs& a, FastCtx& c, uint32_t px, const ptw::PixelRef& ref) {
         c.pxt[px] = (float)ref.i - 0.5f;
-        c.pxt[64 + px] = (float)(a.max_y - ref.j) - 0.5f;
-        c.pxt[128 + px] = __uint_as_float(rng_hash(ref.index ^ a.seed_hash));
+        c.pxt[c.pxs + px] = (float)(a.max_y - ref.j) - 0.5f;
+        c.pxt[2u * c.pxs + px] = __uint_as_float(rng_hash(ref.index ^ a.seed_hash));
     }
     static PTD void start(Path& p, const RenderArgs& a, FastCtx& c, uint32_t px, uint32_t, uint32_t sample) {
-        const uint32_t kpx = __float_as_uint(c.pxt[128 + px]);
+        const uint32_t kpx = __float_as_uint(c.pxt[2u * c.pxs + px]);
         p.key = rng_hash(kpx + 0x9E3779B9u * (sample + 1u));
         float jx, jy;
         rng_pair(p.key, 0u, jx, jy);
-        const float sx = c.pxt[px] + jx, sy = c.pxt[64 + px] + jy;
+        const float sx = c.pxt[px] + jx, sy = c.pxt[c.pxs + px] + jy;
         const V3 cam = v3(a.cam[0], a.cam[1], a.cam[2]);
         const V3 pc = v3(__builtin_fmaf(a.du, sx, a.p00[0]), __builtin_fmaf(a.dv, sy, a.p00[1]), a.p00[2]);
         p.o = cam;
@@ -944,11 +945,11 @@ struct FastTracer {
     }
     // The same in two halves for the ray stash: what depends on the pool item, and what sets up the lane's path.
     static PTD void make_ray(const RenderArgs& a, FastCtx& c, uint32_t px, uint32_t, uint32_t sample, float4& ray) {
-        const uint32_t kpx = __float_as_uint(c.pxt[128 + px]);
+        const uint32_t kpx = __float_as_uint(c.pxt[2u * c.pxs + px]);
         const uint32_t key = rng_hash(kpx + 0x9E3779B9u * (sample + 1u));
         float jx, jy;
         rng_pair(key, 0u, jx, jy);
-        const float sx = c.pxt[px] + jx, sy = c.pxt[64 + px] + jy;
+        const float sx = c.pxt[px] + jx, sy = c.pxt[c.pxs + px] + jy;
         const V3 cam = v3(a.cam[0], a.cam[1], a.cam[2]);
         const V3 pc = v3(__builtin_fmaf(a.du, sx, a.p00[0]), __builtin_fmaf(a.dv, sy, a.p00[1]), a.p00[2]);
         const V3 d = unit(pc - cam);
@@ -1056,6 +1057,7 @@ PTD void carve_wave_lds(uint32_t base, uint32_t P, uint32_t q_cap, BatchLds& L, 
     L.gq = lds_ptr<float4>(base + P * 24u);
     L.stash = L.gq + 4u * q_cap;
     ctx.pxt = reinterpret_cast<float*>(L.stash + 128);
+    ctx.pxs = 64u;
     L.out_px = reinterpret_cast<uint32_t*>(ctx.pxt + 192);
 }
 
@@ -1425,12 +1427,15 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_batched_kernel(RenderA
     ctx.clk.flush(threadIdx.x & 63);
 }
 
+// Dynamic LDS of render_fast_kernel: the walk stacks ([waves][a.walk_stack][64] words, fat hierarchy only), then per
+// wave the parked rays (64 float4), the pixel sums (3 x 64 bit per tile pixel), the pixel table (3 floats per tile
+// pixel) and the framebuffer slots (one word per tile pixel) — sized by the tile, so that small tiles leave room for
+// more workgroups per compute unit.
+__host__ __device__ constexpr uint32_t fast_wave_bytes(uint32_t P) { return 1024u + 40u * P; }
+
 template <bool LDS_TABLES, int BVH, bool SORTED, int KM = KM_ALL>
 __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, uint32_t n_tiles) {
-    __shared__ ptw::WaveLds lds[ptw::WAVES_PER_BLOCK];
-    __shared__ float pxt[ptw::WAVES_PER_BLOCK][192];
-    __shared__ float4 stash[ptw::WAVES_PER_BLOCK][64];
-    extern __shared__ uint32_t wstack[];   // BVH == 2: [waves][a.walk_stack][64], sized by the launch
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     __shared__ FShade lshade[LDS_TABLES ? LDS_MAX_PRIMS : 1];
     __shared__ DMat lmats[LDS_TABLES ? LDS_MAX_MATS : 1];
     FastCtx ctx;
@@ -1450,10 +1455,19 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, u
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t tile = blockIdx.x * ptw::WAVES_PER_BLOCK + wave;
     if (tile >= n_tiles) return;
-    ctx.pxt = pxt[wave];
+    const uint32_t P = 1u << a.tile_log2;
+    const uint32_t stack_words = BVH == 2 ? (uint32_t)ptw::WAVES_PER_BLOCK * (uint32_t)a.walk_stack * 64u : 0u;
+    uint32_t* wstack = reinterpret_cast<uint32_t*>(dyn_lds);
+    unsigned char* mine = dyn_lds + 4u * stack_words + wave * fast_wave_bytes(P);
+    float4* stash = reinterpret_cast<float4*>(mine);
+    ptw::WaveLds lds;
+    lds.acc = reinterpret_cast<unsigned long long*>(mine + 1024u);
+    ctx.pxt = reinterpret_cast<float*>(mine + 1024u + 24u * P);
+    ctx.pxs = P;
+    lds.out_px = reinterpret_cast<uint32_t*>(mine + 1024u + 36u * P);
     ctx.wstack = BVH == 2 ? wstack + wave * ((uint32_t)a.walk_stack * 64u) + (threadIdx.x & 63u) : nullptr;
     ctx.clk.start();
-    ptw::render_tile<FastTracer<BVH, SORTED, KM>>(a, tile, lds[wave], stash[wave], ctx);
+    ptw::render_tile<FastTracer<BVH, SORTED, KM>>(a, tile, lds, stash, ctx);
     ctx.clk.flush(threadIdx.x & 63);
 }
 
@@ -1462,7 +1476,7 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_kernel(RenderArgs a, u
 // they fit.
 template <bool LDS_MATS>
 __global__ __launch_bounds__(ptw::BLOCK) void render_fast_tiled_kernel(RenderArgs a, uint32_t n_tiles) {
-    __shared__ ptw::WaveLds lds[ptw::WAVES_PER_BLOCK];
+    __shared__ ptw::WaveLdsStore lds[ptw::WAVES_PER_BLOCK];
     __shared__ float pxt[ptw::WAVES_PER_BLOCK][192];
     __shared__ __attribute__((aligned(16))) float stage[FDATA_CHUNK];
     __shared__ DMat lmats[LDS_MATS ? LDS_MAX_MATS : 1];
@@ -1480,9 +1494,10 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_tiled_kernel(RenderArg
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t tile = blockIdx.x * ptw::WAVES_PER_BLOCK + wave;
     ctx.pxt = pxt[wave];
+    ctx.pxs = 64u;
     ctx.stage = stage;
     ctx.clk.start();
-    ptw::render_tile_blocksync<FastTracer<0, false>>(a, tile, tile < n_tiles, lds[wave], ctx);
+    ptw::render_tile_blocksync<FastTracer<0, false>>(a, tile, tile < n_tiles, lds[wave].refs(), ctx);
     ctx.clk.flush(threadIdx.x & 63);
 }
 
@@ -1566,6 +1581,7 @@ int ptk_render_fast(const RenderArgs& a, int variant, hipStream_t s) {
     // the 11-primitive scene (4.64 vs 6.66 ms) and on the 10 000-primitive scene (223 vs 249 ms), so PT_MATH_FAST
     // always takes the scalar-load loop; the LDS-staged loop runs only when asked for.
     const bool tiled = variant == PT_MATH_FAST_LDS;
+    const size_t wave_lds = (size_t)fast_wave_bytes(1u << a.tile_log2) * ptw::WAVES_PER_BLOCK;   // of render_fast_kernel
     if (tiled) {
         if (a.n_mats <= LDS_MAX_MATS)
             hipLaunchKernelGGL(render_fast_tiled_kernel<true>, dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
@@ -1576,11 +1592,11 @@ int ptk_render_fast(const RenderArgs& a, int variant, hipStream_t s) {
         if (a.bfat) {
             // the walk stacks: one column of a.walk_stack entries per lane
             const size_t stack_bytes = (size_t)ptw::WAVES_PER_BLOCK * (size_t)a.walk_stack * 64u * sizeof(uint32_t);
-            if (tables) hipLaunchKernelGGL((render_fast_kernel<true, 2, true>), dim3(blocks), dim3(ptw::BLOCK), stack_bytes, s, a, n_tiles);
-            else hipLaunchKernelGGL((render_fast_kernel<false, 2, true>), dim3(blocks), dim3(ptw::BLOCK), stack_bytes, s, a, n_tiles);
+            if (tables) hipLaunchKernelGGL((render_fast_kernel<true, 2, true>), dim3(blocks), dim3(ptw::BLOCK), stack_bytes + wave_lds, s, a, n_tiles);
+            else hipLaunchKernelGGL((render_fast_kernel<false, 2, true>), dim3(blocks), dim3(ptw::BLOCK), stack_bytes + wave_lds, s, a, n_tiles);
         } else {
-            if (tables) hipLaunchKernelGGL((render_fast_kernel<true, 1, true>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
-            else hipLaunchKernelGGL((render_fast_kernel<false, 1, true>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+            if (tables) hipLaunchKernelGGL((render_fast_kernel<true, 1, true>), dim3(blocks), dim3(ptw::BLOCK), wave_lds, s, a, n_tiles);
+            else hipLaunchKernelGGL((render_fast_kernel<false, 1, true>), dim3(blocks), dim3(ptw::BLOCK), wave_lds, s, a, n_tiles);
         }
     } else {
         const bool tables = a.n_prims <= LDS_MAX_PRIMS && a.n_mats <= LDS_MAX_MATS;
@@ -1599,13 +1615,13 @@ int ptk_render_fast(const RenderArgs& a, int variant, hipStream_t s) {
             else { if (short_only) PT_LAUNCH_BATCHED(false, KM_SHORT); else if (general_only) PT_LAUNCH_BATCHED(false, KM_GENERAL); else PT_LAUNCH_BATCHED(false, KM_ALL); }
 #undef PT_LAUNCH_BATCHED
         } else if (sorted) {
-#define PT_LAUNCH_PLAIN(T, KM) hipLaunchKernelGGL((render_fast_kernel<T, 0, true, KM>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles)
+#define PT_LAUNCH_PLAIN(T, KM) hipLaunchKernelGGL((render_fast_kernel<T, 0, true, KM>), dim3(blocks), dim3(ptw::BLOCK), wave_lds, s, a, n_tiles)
             if (tables) { if (short_only) PT_LAUNCH_PLAIN(true, KM_SHORT); else if (general_only) PT_LAUNCH_PLAIN(true, KM_GENERAL); else PT_LAUNCH_PLAIN(true, KM_ALL); }
             else { if (short_only) PT_LAUNCH_PLAIN(false, KM_SHORT); else if (general_only) PT_LAUNCH_PLAIN(false, KM_GENERAL); else PT_LAUNCH_PLAIN(false, KM_ALL); }
 #undef PT_LAUNCH_PLAIN
         } else {
-            if (tables) hipLaunchKernelGGL((render_fast_kernel<true, 0, false>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
-            else hipLaunchKernelGGL((render_fast_kernel<false, 0, false>), dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+            if (tables) hipLaunchKernelGGL((render_fast_kernel<true, 0, false>), dim3(blocks), dim3(ptw::BLOCK), wave_lds, s, a, n_tiles);
+            else hipLaunchKernelGGL((render_fast_kernel<false, 0, false>), dim3(blocks), dim3(ptw::BLOCK), wave_lds, s, a, n_tiles);
         }
     }
     PT_CHECK(hipGetLastError());

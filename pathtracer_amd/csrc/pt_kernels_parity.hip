@@ -45,13 +45,13 @@ struct ParityTracer {
 };
 
 __global__ __launch_bounds__(ptw::BLOCK) void render_parity_kernel(RenderArgs a, uint32_t n_tiles) {
-    __shared__ ptw::WaveLds lds[ptw::WAVES_PER_BLOCK];
+    __shared__ ptw::WaveLdsStore lds[ptw::WAVES_PER_BLOCK];
     __shared__ float4 stash[ptw::WAVES_PER_BLOCK][64];
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t tile = blockIdx.x * ptw::WAVES_PER_BLOCK + wave;
     if (tile >= n_tiles) return;
     ParityCtx ctx;
-    ptw::render_tile<ParityTracer>(a, tile, lds[wave], stash[wave], ctx);
+    ptw::render_tile<ParityTracer>(a, tile, lds[wave].refs(), stash[wave], ctx);
 }
 
 __device__ __forceinline__ V3 load3(const float* p, int i) { return v3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }

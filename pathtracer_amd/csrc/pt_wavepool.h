@@ -26,9 +26,16 @@ constexpr int BLOCK = 64 * WAVES_PER_BLOCK;
 constexpr int ACC_WORDS = 64 * 3;   // 64-bit accumulators per wave
 
 // LDS of one wave: accumulators and where each tile pixel goes in the framebuffer.
+// Per-wave arrays in LDS: the tile's pixel sums (3 per pixel) and each pixel's framebuffer slot.
 struct WaveLds {
+    unsigned long long* acc;
+    uint32_t* out_px;
+};
+// The same as static storage for a tile of up to 64 pixels.
+struct WaveLdsStore {
     unsigned long long acc[ACC_WORDS];
     uint32_t out_px[64];
+    __device__ __forceinline__ WaveLds refs() { WaveLds l; l.acc = acc; l.out_px = out_px; return l; }
 };
 
 __device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -68,7 +75,7 @@ __device__ __forceinline__ float from_fixed(unsigned long long v) {
     return (float)(int)(v >> 32) + (float)(unsigned)v * 2.3283064365386963e-10f;
 }
 
-__device__ __forceinline__ void add_sample(WaveLds& l, uint32_t px, const float rgb[3], float cap) {
+__device__ __forceinline__ void add_sample(const WaveLds& l, uint32_t px, const float rgb[3], float cap) {
     // most paths end without having met a light: a zero adds nothing to a fixed-point sum (nor does a negative zero)
     if (rgb[0] == 0.0f && rgb[1] == 0.0f && rgb[2] == 0.0f) return;
     for (int c = 0; c < 3; c++)
@@ -105,14 +112,14 @@ __device__ __forceinline__ void store_tile(const RenderArgs& a, const WaveLds& l
 // them in `stash` (LDS, one float4 per item: direction and RNG key); a lane that needs work takes the next parked ray.
 // Items are handed out in pool order, lane by lane.
 template <class T, class Ctx>
-__device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, WaveLds& l, float4* stash, Ctx& ctx) {
+__device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, const WaveLds& l, float4* stash, Ctx& ctx) {
     const unsigned lane = lane_id();
     const uint32_t lg = (uint32_t)a.tile_log2, P = 1u << lg;
     const uint32_t lin_base = tile << lg;
     const uint32_t npx = min(P, a.n_lin - lin_base);
     const uint32_t total = (uint32_t)a.n_samples << lg;
 
-    l.acc[lane] = 0ull; l.acc[lane + 64] = 0ull; l.acc[lane + 128] = 0ull;
+    for (uint32_t f = lane; f < 3u * P; f += 64u) l.acc[f] = 0ull;
     if (lane < npx) {
         const PixelRef ref = pixel_of(a, lin_base + lane);
         l.out_px[lane] = ref.out;
@@ -191,14 +198,14 @@ __device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, 
 //                           static Best nearest_block(const Path&, const RenderArgs&, Ctx&);   // contains barriers
 //                           static bool shade(Path&, const Best&, const RenderArgs&, Ctx&);    // true = path continues
 template <class T, class Ctx>
-__device__ __forceinline__ void render_tile_blocksync(const RenderArgs& a, uint32_t tile, bool tile_valid, WaveLds& l, Ctx& ctx) {
+__device__ __forceinline__ void render_tile_blocksync(const RenderArgs& a, uint32_t tile, bool tile_valid, const WaveLds& l, Ctx& ctx) {
     const unsigned lane = lane_id();
     const uint32_t lg = (uint32_t)a.tile_log2, P = 1u << lg;
     const uint32_t lin_base = tile_valid ? tile << lg : 0u;
     const uint32_t npx = tile_valid ? min(P, a.n_lin - lin_base) : 0u;
     const uint32_t total = tile_valid ? (uint32_t)a.n_samples << lg : 0u;
 
-    l.acc[lane] = 0ull; l.acc[lane + 64] = 0ull; l.acc[lane + 128] = 0ull;
+    for (uint32_t f = lane; f < 3u * P; f += 64u) l.acc[f] = 0ull;
     if (lane < npx) {
         const PixelRef ref = pixel_of(a, lin_base + lane);
         l.out_px[lane] = ref.out;

@@ -24,14 +24,14 @@ stats() {   # name, program words...
 }
 stats config2 python3 "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline
 stats config4_glass5_depth31 python3 "$R/tools/profile_frame.py" glass5 1920 1080 64 31 reps=8
-stats config5_10k_prims python3 "$R/tools/profile_frame.py" synthetic 1920 1080 4 5 reps=8
+stats config5_10k_prims python3 "$R/tools/profile_frame.py" synthetic 1920 1080 16 5 reps=8
 stats config2_general_kinds python3 "$R/tools/profile_frame.py" default 1920 1080 64 5 general reps=8
 
 cd "$R"
 step bash tools/pmc_passes.sh "$OUT/pmc_config2"
 export PROG=tools/profile_frame.py
 step bash tools/pmc_passes.sh "$OUT/pmc_config4_glass5_depth31" glass5 1920 1080 64 31
-step bash tools/pmc_passes.sh "$OUT/pmc_config5_10k_prims" synthetic 1920 1080 4 5
+step bash tools/pmc_passes.sh "$OUT/pmc_config5_10k_prims" synthetic 1920 1080 16 5
 step bash tools/pmc_passes.sh "$OUT/pmc_config2_general_kinds" default 1920 1080 64 5 general
 unset PROG
 
