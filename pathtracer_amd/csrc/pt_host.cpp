@@ -477,10 +477,29 @@ int bvh_min_levels(int n, int leaf_prims) {
 
 // The fat form of a skip-link tree whose leaves hold one primitive each: one entry per inner node, in the same
 // depth-first order, each with the boxes and references of its two children (left child = next node, right child =
-// the left child's skip link).
+// the left child's skip link), the boxes on a 16-bit grid over the root's box (origin + step * q; a box only grows).
 // Returns the depth of the deepest leaf (the root's children are at depth 1): the walk parks at most one reference
 // per level, so this is the stack height a lane can need.
-int build_fat(const std::vector<BNode>& nodes, std::vector<BFat>& fat) {
+int build_fat(const std::vector<BNode>& nodes, std::vector<BFat>& fat, float origin[3], float step[3]) {
+    for (int k = 0; k < 3; k++) {
+        origin[k] = nodes[0].lo[k];
+        step[k] = (nodes[0].hi[k] - nodes[0].lo[k]) / 65535.0f * (1.0f + 1e-6f);
+        if (!(step[k] > 0.0f)) step[k] = 1e-30f;       // a flat box: every coordinate is the origin
+    }
+    // the largest q with origin + step * q <= x, and the smallest with origin + step * q >= x, as the float
+    // arithmetic has it
+    auto below = [&](float x, int k) {
+        int q = (int)std::floor((x - origin[k]) / step[k]);
+        q = std::min(std::max(q, 0), 65535);
+        while (q > 0 && std::fmaf(step[k], (float)q, origin[k]) > x) q--;
+        return (uint16_t)q;
+    };
+    auto above = [&](float x, int k) {
+        int q = (int)std::ceil((x - origin[k]) / step[k]);
+        q = std::min(std::max(q, 0), 65535);
+        while (q < 65535 && std::fmaf(step[k], (float)q, origin[k]) < x) q++;
+        return (uint16_t)q;
+    };
     std::vector<int32_t> fat_index(nodes.size(), -1);
     int32_t n_inner = 0;
     for (size_t i = 0; i < nodes.size(); i++) if (nodes[i].leaf < 0) fat_index[i] = n_inner++;
@@ -492,8 +511,8 @@ int build_fat(const std::vector<BNode>& nodes, std::vector<BFat>& fat) {
         BFat& f = fat[(size_t)fat_index[i]];
         std::memset(&f, 0, sizeof(f));
         for (int k = 0; k < 3; k++) {
-            f.lo_a[k] = nodes[a].lo[k]; f.hi_a[k] = nodes[a].hi[k];
-            f.lo_b[k] = nodes[b].lo[k]; f.hi_b[k] = nodes[b].hi[k];
+            f.lo_a[k] = below(nodes[a].lo[k], k); f.hi_a[k] = above(nodes[a].hi[k], k);
+            f.lo_b[k] = below(nodes[b].lo[k], k); f.hi_b[k] = above(nodes[b].hi[k], k);
         }
         f.ref_a = ref_of(a); f.ref_b = ref_of(b);
     }
@@ -642,6 +661,7 @@ int pt_scene_upload_opt(const pt_prim* prims, int n_prims, const pt_material* ma
     std::vector<BPrim> bprims;
     std::vector<BFat> bfat;
     int fat_depth = 0;
+    float fat_origin[3] = {0.0f, 0.0f, 0.0f}, fat_step[3] = {1.0f, 1.0f, 1.0f};
     const int bvh_min = o.bvh_min_prims ? o.bvh_min_prims : BVH_MIN_PRIMS;
     if ((int)finite.size() >= bvh_min) {
         const int leaf_prims = o.bvh_leaf_prims ? o.bvh_leaf_prims : BVH_LEAF_PRIMS;
@@ -650,7 +670,7 @@ int pt_scene_upload_opt(const pt_prim* prims, int n_prims, const pt_material* ma
         const int slack = split >= PT_BVH_SPLIT_AREA ? split - PT_BVH_SPLIT_AREA : 0;
         build_bvh(build, finite, 0, (int)finite.size(), bvh_min_levels((int)finite.size(), leaf_prims) + slack);
         if (leaf_prims == 1 && finite.size() >= 2 && (int)finite.size() <= BFAT_MAX_PRIMS) {
-            fat_depth = build_fat(bnodes, bfat);
+            fat_depth = build_fat(bnodes, bfat, fat_origin, fat_step);
             if (fat_depth > WALK_STACK_MAX) bfat.clear();   // cannot happen: the builder keeps <= 2^19 leaves within 19 + 5 levels
         }
         if (top.empty()) {   // the loop over the other primitives still wants one (empty) chunk to read
@@ -693,7 +713,11 @@ int pt_scene_upload_opt(const pt_prim* prims, int n_prims, const pt_material* ma
     if (!bnodes.empty()) {
         UP(d_bnodes, bnodes, BNode)
         UP(d_bprims, bprims, BPrim)
-        if (!bfat.empty()) { UP(d_bfat, bfat, BFat) sc->fat_depth = fat_depth; }
+        if (!bfat.empty()) {
+            UP(d_bfat, bfat, BFat)
+            sc->fat_depth = fat_depth;
+            for (int k = 0; k < 3; k++) { sc->fat_origin[k] = fat_origin[k]; sc->fat_step[k] = fat_step[k]; }
+        }
         UP(d_sorted_top, sorted_top, float)
         sc->sorted_top = hdr_top; sc->sorted_top.data = sc->d_sorted_top;
         UP(d_fdata_top, fdata_top, float)
@@ -817,6 +841,7 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
         // PT_MATH_FAST_SCALAR and PT_MATH_FAST_LDS keep testing every primitive.
         a.bnodes = sc->d_bnodes; a.bprims = sc->d_bprims; a.n_bnodes = sc->n_bnodes;
         a.bfat = sc->d_bfat; a.walk_stack = sc->fat_depth;
+        for (int k = 0; k < 3; k++) { a.fat_origin[k] = sc->fat_origin[k]; a.fat_step[k] = sc->fat_step[k]; }
         if (sc->tune[PT_TUNE_BVH_WALK] == 1) a.bfat = nullptr;
         a.fdata = sc->d_fdata_top; a.runs = sc->d_runs_top; a.n_runs = sc->n_runs_top;
         a.sorted = sc->sorted_top;

@@ -104,15 +104,18 @@ struct BPrim {
     int32_t pad[2];
 };
 // The same tree with both children's boxes in the parent, for the ordered walk with a per-lane stack: one visit
-// fetches 64 bytes and decides about two subtrees.  A child reference is an index into this array (>= 0) or, for a
-// one-primitive leaf, ~(index into the BPrim array).  Built when every leaf holds one primitive and the tree has at
-// most 2^19 of them (references are packed into 20 bits on the stack).
+// fetches 32 bytes and decides about two subtrees.  The boxes are 16-bit coordinates on the grid that spans the box
+// of all finite primitives (coordinate = origin + step * q per axis, pt_scene::fat_origin / fat_step; lo rounded
+// down, hi rounded up, so a box only grows): the walk is bound by the vector memory path, and a node of floats would
+// be twice the fetches.  A child reference is an index into this array (>= 0) or, for a one-primitive leaf,
+// ~(index into the BPrim array).  Built when every leaf holds one primitive and the tree has at most 2^19 of them
+// (references are packed into 20 bits on the stack).
 struct BFat {
-    float lo_a[3]; int32_t ref_a;
-    float hi_a[3]; int32_t ref_b;
-    float lo_b[3]; int32_t pad0;
-    float hi_b[3]; int32_t pad1;
+    uint16_t lo_a[3], hi_a[3];
+    uint16_t lo_b[3], hi_b[3];
+    int32_t ref_a, ref_b;
 };
+static_assert(sizeof(BFat) == 32, "two 16-byte fetches per node");
 constexpr int BFAT_MAX_PRIMS = 1 << 19;
 constexpr int WALK_STACK_MAX = 24;    // stack entries per lane: the builder keeps 2^19 leaves within 19 + 5 levels
 constexpr int WALK_NONE = 0x7fffffff; // "no node in hand": the next one comes off the stack
@@ -147,6 +150,7 @@ struct pt_scene {
     FSorted sorted_top;
     BFat* d_bfat;                          // or null: only the skip-link form exists
     int fat_depth;                         // depth of its deepest leaf = stack entries a lane can need
+    float fat_origin[3], fat_step[3];      // the grid of its box coordinates
     float* d_fdata_top;
     FRun* d_runs_top;
     int n_runs_top;
@@ -185,6 +189,7 @@ struct RenderArgs {
     const BPrim* bprims;
     FSorted sorted;                        // PT_MATH_FAST: the primitives the typed loops test (all, or those outside the hierarchy)
     const BFat* bfat;                      // non-null: walk this form (ordered, per-lane stack in LDS)
+    float fat_origin[3], fat_step[3];
     int32_t walk_stack;                    // stack entries per lane the launch provides (dynamic LDS)
     int32_t n_bnodes;
     int32_t walk_budget;                   // hierarchy nodes a lane visits per loop iteration

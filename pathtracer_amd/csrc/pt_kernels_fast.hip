@@ -493,14 +493,15 @@ PTD void walk_hierarchy(V3 o, V3 d, float dd, float idd, const BNode* __restrict
 // The control flow is the wave's, not the lane's: every trip of the node loop is, for each lane, an optional pop
 // followed by an optional visit, and the wave leaves the loop when no lane can go on, when `leaf_gate` lanes hold a
 // leaf, or after `budget` trips; then the lanes that hold a leaf test it together, its whole record fetched at once.
-PTD void walk_fat(V3 o, V3 d, float dd, float idd, const BFat* __restrict__ fat, const BPrim* __restrict__ prims,
-                  Best& b, int& cur, int& sp, uint32_t* stack, int budget, int leaf_gate) {
+PTD void walk_fat(V3 o, V3 d, float dd, float idd, const BFat* __restrict__ fat, V3 origin, V3 step,
+                  const BPrim* __restrict__ prims, Best& b, int& cur, int& sp, uint32_t* stack, int budget, int leaf_gate) {
     // 1/d kept finite (+-1e30): with an infinite reciprocal, plane*inv - o*inv is inf - inf = NaN for every box on the
     // origin's side of an axis the ray does not move along, v_min/v_max drop the NaN, and that axis never culls — the
     // walk stays correct but an axis-parallel ray would descend most of the tree
     const V3 inv = v3(__builtin_amdgcn_fmed3f(rcp(d.x), -1e30f, 1e30f), __builtin_amdgcn_fmed3f(rcp(d.y), -1e30f, 1e30f),
                       __builtin_amdgcn_fmed3f(rcp(d.z), -1e30f, 1e30f));
-    const V3 noi = v3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+    // a box plane at grid coordinate q is met at (origin + step*q - o) * inv = q * ga + gb
+    const V3 ga = step * inv, gb = (origin - o) * inv;
     for (;;) {
         for (; budget > 0; budget--) {
             budget = __builtin_amdgcn_readfirstlane(budget);
@@ -515,22 +516,26 @@ PTD void walk_fat(V3 o, V3 d, float dd, float idd, const BFat* __restrict__ fat,
             CENSUS(0, 1); CENSUS(1, __popcll(__ballot(inner))); CENSUS(2, __popcll(__ballot(cur < 0)));
             CENSUS(3, __popcll(__ballot(cur == WALK_NONE && sp == 0))); CENSUS(4, __popcll(__ballot(pending))); CENSUS(5, __popcll(__ballot(true)));
             if (inner) {
-                const float4* N = reinterpret_cast<const float4*>(fat + cur);
-                const float4 A0 = N[0], A1 = N[1], B0 = N[2], B1 = N[3];
-                // slab tests of both boxes as plane*inv - o*inv (inv is finite, see above; an origin exactly on a plane
-                // of an axis the ray does not move along gives 0 * 1e30 = 0: inside that slab)
-                const float a0x = __builtin_fmaf(A0.x, inv.x, noi.x), a1x = __builtin_fmaf(A1.x, inv.x, noi.x);
-                const float a0y = __builtin_fmaf(A0.y, inv.y, noi.y), a1y = __builtin_fmaf(A1.y, inv.y, noi.y);
-                const float a0z = __builtin_fmaf(A0.z, inv.z, noi.z), a1z = __builtin_fmaf(A1.z, inv.z, noi.z);
-                const float b0x = __builtin_fmaf(B0.x, inv.x, noi.x), b1x = __builtin_fmaf(B1.x, inv.x, noi.x);
-                const float b0y = __builtin_fmaf(B0.y, inv.y, noi.y), b1y = __builtin_fmaf(B1.y, inv.y, noi.y);
-                const float b0z = __builtin_fmaf(B0.z, inv.z, noi.z), b1z = __builtin_fmaf(B1.z, inv.z, noi.z);
+                const uint4* N = reinterpret_cast<const uint4*>(fat + cur);
+                const uint4 W0 = N[0], W1 = N[1];
+                // slab tests of both boxes (inv is finite, see above; an origin exactly on a plane of an axis the ray
+                // does not move along gives 0 * 1e30 = 0: inside that slab)
+#define PT_GRID_LO(w) ((float)((w) & 0xFFFFu))
+#define PT_GRID_HI(w) ((float)((w) >> 16))
+                const float a0x = __builtin_fmaf(PT_GRID_LO(W0.x), ga.x, gb.x), a0y = __builtin_fmaf(PT_GRID_HI(W0.x), ga.y, gb.y);
+                const float a0z = __builtin_fmaf(PT_GRID_LO(W0.y), ga.z, gb.z), a1x = __builtin_fmaf(PT_GRID_HI(W0.y), ga.x, gb.x);
+                const float a1y = __builtin_fmaf(PT_GRID_LO(W0.z), ga.y, gb.y), a1z = __builtin_fmaf(PT_GRID_HI(W0.z), ga.z, gb.z);
+                const float b0x = __builtin_fmaf(PT_GRID_LO(W0.w), ga.x, gb.x), b0y = __builtin_fmaf(PT_GRID_HI(W0.w), ga.y, gb.y);
+                const float b0z = __builtin_fmaf(PT_GRID_LO(W1.x), ga.z, gb.z), b1x = __builtin_fmaf(PT_GRID_HI(W1.x), ga.x, gb.x);
+                const float b1y = __builtin_fmaf(PT_GRID_LO(W1.y), ga.y, gb.y), b1z = __builtin_fmaf(PT_GRID_HI(W1.y), ga.z, gb.z);
+#undef PT_GRID_LO
+#undef PT_GRID_HI
                 const float tna = max3(__builtin_fminf(a0x, a1x), __builtin_fminf(a0y, a1y), __builtin_fmaxf(__builtin_fminf(a0z, a1z), 0.0f));
                 const float tfa = min3(__builtin_fmaxf(a0x, a1x), __builtin_fmaxf(a0y, a1y), __builtin_fminf(__builtin_fmaxf(a0z, a1z), b.t));
                 const float tnb = max3(__builtin_fminf(b0x, b1x), __builtin_fminf(b0y, b1y), __builtin_fmaxf(__builtin_fminf(b0z, b1z), 0.0f));
                 const float tfb = min3(__builtin_fmaxf(b0x, b1x), __builtin_fmaxf(b0y, b1y), __builtin_fminf(__builtin_fmaxf(b0z, b1z), b.t));
                 const bool ha = tna <= tfa, hb = tnb <= tfb;
-                const int ra = __float_as_int(A0.w), rb = __float_as_int(A1.w);
+                const int ra = (int)W1.z, rb = (int)W1.w;
                 const bool a_first = tna <= tnb;
                 const int far = a_first ? rb : ra, near = a_first ? ra : rb;
                 const float tfar = a_first ? tnb : tna;
@@ -839,6 +844,7 @@ struct SceneRefs {
     const BPrim* bprims;
     int n_nodes;
     const BFat* fat;
+    V3 fat_origin, fat_step;
     FSorted sorted;       // data == null: loop over the runs instead
 };
 
@@ -881,7 +887,7 @@ PTD bool path_step_walk(WalkPath& p, const SceneRefs& sc, const FShade* shade, c
     PHASE(clk, 7);
     bool done;
     if (FAT) {
-        walk_fat(p.o, p.d, dd, idd, sc.fat, sc.bprims, p.best, p.node, p.sp, stack, walk_budget, leaf_gate);
+        walk_fat(p.o, p.d, dd, idd, sc.fat, sc.fat_origin, sc.fat_step, sc.bprims, p.best, p.node, p.sp, stack, walk_budget, leaf_gate);
         done = p.node == WALK_NONE && p.sp == 0;
     } else {
         walk_hierarchy(p.o, p.d, dd, idd, sc.nodes, sc.n_nodes, sc.bprims, p.best, p.node, walk_budget);
@@ -970,6 +976,7 @@ struct FastTracer {
         SceneRefs sc;
         sc.fdata = a.fdata; sc.runs = a.runs; sc.n_runs = a.n_runs;
         sc.nodes = a.bnodes; sc.bprims = a.bprims; sc.n_nodes = a.n_bnodes; sc.fat = a.bfat; sc.sorted = a.sorted;
+        sc.fat_origin = v3(a.fat_origin[0], a.fat_origin[1], a.fat_origin[2]); sc.fat_step = v3(a.fat_step[0], a.fat_step[1], a.fat_step[2]);
         return step_path(p, sc, a, c);
     }
     static PTD bool step_path(ptf::Path& p, const SceneRefs& sc, const RenderArgs& a, FastCtx& c) {

@@ -14,13 +14,13 @@ def timed():
         e0.record(); sc.render(cfg, out=out); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     return min(ts)
-for walk, leaf_gates in (("fat", (8, 16)), ("skip", (0,))):
+for walk, leaf_gates in (("fat", (4, 8, 16)),):
     sc.tune(pt.binding.PT_TUNE_BVH_WALK, 1 if walk == "skip" else 0)
     for leaf_gate in leaf_gates:
         sc.tune(pt.binding.PT_TUNE_LEAF_GATE, leaf_gate)
-        for budget in (16, 32, 64, 128, 1000000):
+        for budget in (8, 12, 16, 24, 32):
             row = []
-            for gate in (4, 8, 12, 16, 24, 32):
+            for gate in (1, 8, 16, 24):
                 sc.tune(pt.binding.PT_TUNE_WALK_BUDGET, budget).tune(pt.binding.PT_TUNE_SHADE_GATE, gate)
                 row.append("%.2f" % timed())
-            print(walk, "leaf gate", leaf_gate, "budget", budget, "shade gate 4/8/12/16/24/32:", " ".join(row), flush=True)
+            print(walk, "leaf gate", leaf_gate, "budget", budget, "shade gate 1/8/16/24:", " ".join(row), flush=True)
