@@ -98,6 +98,7 @@ def main():
             rows_out.append(rec)
             print(json.dumps(rec), flush=True)
     if len(sys.argv) > 1:
+        os.makedirs(os.path.dirname(os.path.abspath(sys.argv[1])), exist_ok=True)
         json.dump(rows_out, open(sys.argv[1], "w"), indent=1)
 
 
