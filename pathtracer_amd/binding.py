@@ -48,6 +48,7 @@ class pt_upload_options(C.Structure):
 
 
 PT_GENERAL_PLANES, PT_GENERAL_CUBES, PT_GENERAL_SPHERES, PT_GENERAL_ALL = 1, 2, 4, 7
+PT_BVH_SPLIT_MEDIAN, PT_BVH_SPLIT_AREA = 1, 2
 PT_TUNE_TILE_LOG2, PT_TUNE_WALK_BUDGET, PT_TUNE_SHADE_GATE, PT_TUNE_BVH_WALK, PT_TUNE_GLASS_QUEUE, PT_TUNE_GLASS_GATE, PT_TUNE_LEAF_GATE = range(7)
 
 

@@ -144,6 +144,22 @@ def test_hierarchy_equals_loop_over_all_primitives_bitwise():
         b = sc.render(pt.make_config(w, h, spp, n_bounces=depth, math_mode=pt.PT_MATH_FAST_SCALAR))
         assert torch.isfinite(a).all() and float(a.sum()) > 0.0
         assert torch.equal(a, b)
+    # every way of building and walking the tree gives that image too: the split rules, leaves of several primitives
+    # (skip-link walk), the skip-link walk of one-primitive leaves
+    scene, (w, h, spp, depth) = cases[3]
+    ref = pt.Scene(*scene).render(pt.make_config(w, h, spp, n_bounces=depth, math_mode=pt.PT_MATH_FAST_SCALAR))
+    for options, walk in (({"bvh_split": pt.binding.PT_BVH_SPLIT_MEDIAN}, 0), ({"bvh_split": pt.binding.PT_BVH_SPLIT_AREA}, 0),
+                          ({"bvh_split": pt.binding.PT_BVH_SPLIT_AREA + 5}, 0), ({"bvh_leaf_prims": 4}, 0), ({}, 1)):
+        sc = pt.Scene(*scene, **options)
+        assert sc.bvh_nodes > 0
+        if walk:
+            sc.tune(pt.binding.PT_TUNE_BVH_WALK, walk)
+        assert torch.equal(sc.render(pt.make_config(w, h, spp, n_bounces=depth, math_mode=pt.PT_MATH_FAST)), ref), (options, walk)
+    # 100 000 primitives: the grid of the node boxes is 16 bits per axis over the whole scene
+    sc = pt.Scene(*pt.synthetic_scene(50000, 50000, 99))
+    a = sc.render(pt.make_config(96, 54, 2, math_mode=pt.PT_MATH_FAST))
+    b = sc.render(pt.make_config(96, 54, 2, math_mode=pt.PT_MATH_FAST_SCALAR))
+    assert float(a.sum()) > 0.0 and torch.equal(a, b)
     # explicit rays through tracePath: the hierarchy there too, against the parity-order kernel's loop
     prims, n, mats, nm = pt.parse_scene(_mixed_scene_text(120))
     sc = pt.Scene(prims, n, mats, nm)
