@@ -1,4 +1,4 @@
-"""Prints the result table of BASELINE.md section 5 from profiles/r02/config_table.json and the counter passes beside it.
+"""Prints the result table of the five benchmark configurations (markdown) from profiles/r02/config_table.json and the counter passes beside it.
     python3 tools/baseline_table.py"""
 import json
 import os
