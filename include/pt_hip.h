@@ -49,7 +49,8 @@ typedef struct pt_prim {
 
 /* Math mode of pt_render. */
 enum {
-    PT_MATH_PARITY = 0, /* reference operation order, IEEE div/sqrt, no FMA contraction */
+    PT_MATH_PARITY = 0, /* reference operation order, IEEE div/sqrt, no FMA contraction; a scene with a bounding-volume
+                         * hierarchy (below) is searched through it, with the same result as the reference's loop */
     PT_MATH_FAST = 1,   /* same algorithm, FMA + v_rcp/v_rsq/v_sin/v_cos, restructured tests; scenes with
                          * 60 or more finite primitives are searched through a bounding-volume hierarchy
                          * (same nearest hit as the loop of shapes.h:82-98, lowest index on ties) */
@@ -130,7 +131,8 @@ enum {
     PT_TUNE_TILE_LOG2 = 0,   /* log2 of the pixels per wave (2..6) when pt_config.tile_log2 is 0 */
     PT_TUNE_WALK_BUDGET = 1, /* hierarchy nodes a lane visits (or takes off its stack) per loop iteration (>= 1) */
     PT_TUNE_SHADE_GATE = 2,  /* lanes whose hierarchy search is over before they are shaded together (1..64) */
-    PT_TUNE_BVH_WALK = 3,    /* 1: walk the hierarchy in its skip-link form instead of the two-children-per-node form */
+    PT_TUNE_BVH_WALK = 3,    /* 1: PT_MATH_FAST walks the hierarchy in its skip-link form instead of the two-children-per-node
+                              * form; 3: PT_MATH_PARITY loops over all primitives although the scene has a hierarchy */
     PT_TUNE_GLASS_QUEUE = 4, /* PT_MATH_FAST, no hierarchy: entries per wave of the LDS queue in which hits on glass
                               * wait to be shaded together (8..64); -1: no queue, every hit is shaded where it is found */
     PT_TUNE_GLASS_GATE = 5,  /* queue entries from which free lanes take them back (1..queue size) */

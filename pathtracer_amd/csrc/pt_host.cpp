@@ -718,6 +718,8 @@ int pt_scene_upload_opt(const pt_prim* prims, int n_prims, const pt_material* ma
             sc->fat_depth = fat_depth;
             for (int k = 0; k < 3; k++) { sc->fat_origin[k] = fat_origin[k]; sc->fat_step[k] = fat_step[k]; }
         }
+        if (!top.empty()) { UP(d_top_ids, top, int32_t) }
+        sc->n_top_ids = (int)top.size();
         UP(d_sorted_top, sorted_top, float)
         sc->sorted_top = hdr_top; sc->sorted_top.data = sc->d_sorted_top;
         UP(d_fdata_top, fdata_top, float)
@@ -742,6 +744,7 @@ int pt_scene_free(pt_scene* sc) {
     if (sc->d_bnodes) (void)hipFree(sc->d_bnodes);
     if (sc->d_bprims) (void)hipFree(sc->d_bprims);
     if (sc->d_bfat) (void)hipFree(sc->d_bfat);
+    if (sc->d_top_ids) (void)hipFree(sc->d_top_ids);
     if (sc->d_sorted) (void)hipFree(sc->d_sorted);
     if (sc->d_slot_box) (void)hipFree(sc->d_slot_box);
     if (sc->d_sorted_top) (void)hipFree(sc->d_sorted_top);
@@ -751,6 +754,19 @@ int pt_scene_free(pt_scene* sc) {
     return 0;
 }
 
+}  // extern "C"
+
+PScene pt_parity_scene(const pt_scene* sc) {
+    PScene p;
+    p.prims = sc->d_prims; p.n_prims = sc->n_prims;
+    p.nodes = sc->d_bnodes; p.n_nodes = sc->n_bnodes; p.bprims = sc->d_bprims;
+    p.top = sc->d_top_ids; p.n_top = sc->n_top_ids;
+    if (sc->tune[PT_TUNE_BVH_WALK] == 3) { p.nodes = nullptr; p.n_nodes = 0; }    // the loop over all primitives is asked for
+    return p;
+}
+
+extern "C" {
+
 int pt_scene_tune(pt_scene* sc, int knob, int value) {
     if (!sc || knob < 0 || knob >= PT_TUNE_COUNT) return PT_FAIL("pt_scene_tune: bad scene or knob");
     bool ok = value == 0;
@@ -758,7 +774,7 @@ int pt_scene_tune(pt_scene* sc, int knob, int value) {
         case PT_TUNE_TILE_LOG2: ok = ok || (value >= 2 && value <= 6); break;
         case PT_TUNE_WALK_BUDGET: ok = ok || value >= 1; break;
         case PT_TUNE_SHADE_GATE: ok = ok || (value >= 1 && value <= 64); break;
-        case PT_TUNE_BVH_WALK: ok = ok || value == 1; break;
+        case PT_TUNE_BVH_WALK: ok = ok || value == 1 || value == 3; break;
         case PT_TUNE_GLASS_QUEUE: ok = ok || value == -1 || (value >= 8 && value <= 64); break;
         case PT_TUNE_GLASS_GATE: ok = ok || (value >= 1 && value <= 64); break;
         case PT_TUNE_LEAF_GATE: ok = ok || (value >= 1 && value <= 64); break;
@@ -833,6 +849,7 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     a.fb_layout = cfg->fb_layout;
     a.n_prims = sc->n_prims; a.n_mats = sc->n_mats;
     a.prims = sc->d_prims; a.mats = sc->d_mats;
+    a.pscene = pt_parity_scene(sc);
     a.fdata = sc->d_fdata; a.runs = sc->d_runs; a.n_runs = sc->n_runs; a.fshade = sc->d_fshade;
     a.chunk_runs = sc->d_chunk_runs; a.n_chunks = sc->n_chunks;
     a.sorted = sc->sorted;

@@ -128,6 +128,18 @@ constexpr int BVH_LEAF_PRIMS = 1;     // measured on the 10 000-primitive scene:
 
 
 
+// What a parity-order nearest-hit search reads of a scene: the primitive table and, when the scene has a hierarchy
+// (nodes != null), its skip-link form and the scene indices, ascending, of the primitives outside it (the planes).
+struct PScene {
+    const DPrim* prims;
+    int32_t n_prims;
+    const BNode* nodes;
+    int32_t n_nodes;
+    const BPrim* bprims;
+    const int32_t* top;
+    int32_t n_top;
+};
+
 struct pt_scene {
     int device;
     int n_prims;
@@ -150,6 +162,8 @@ struct pt_scene {
     FSorted sorted_top;
     BFat* d_bfat;                          // or null: only the skip-link form exists
     int fat_depth;                         // depth of its deepest leaf = stack entries a lane can need
+    int32_t* d_top_ids;                    // scene indices of the primitives outside the hierarchy, ascending
+    int n_top_ids;
     float fat_origin[3], fat_step[3];      // the grid of its box coordinates
     float* d_fdata_top;
     FRun* d_runs_top;
@@ -177,6 +191,7 @@ struct RenderArgs {
     int32_t tile_log2;                     // pixels per wave tile = 1 << tile_log2 (2..6)
     int32_t fb_layout;
     int32_t n_prims, n_mats;
+    PScene pscene;                         // the same scene for the parity-order search
     const DPrim* prims;
     const DMat* mats;
     const float* fdata;
@@ -206,6 +221,7 @@ struct RenderArgs {
 };
 
 // Kernel launchers implemented in the .hip translation units.
+PScene pt_parity_scene(const pt_scene* sc);
 int ptk_render_parity(const RenderArgs& a, hipStream_t s);
 int ptk_render_fast(const RenderArgs& a, int variant, hipStream_t s);   // variant: PT_MATH_FAST (auto), _SCALAR, _LDS
 int ptk_raypath_batch(const pt_scene* sc, int prim, const float* o, const float* d, int n, int filter,

@@ -35,8 +35,8 @@ struct ParityTracer {
     }
     static __device__ __forceinline__ void prologue(const RenderArgs&, ParityCtx&, uint32_t, const ptw::PixelRef&) {}
     static __device__ __forceinline__ bool step(Path& p, const RenderArgs& a, ParityCtx&) {
-        if (a.bsdf_model == PT_BSDF_CLASSES) return path_step_alt(p, a.prims, a.n_prims, a.mats, a.n_bounces);
-        return path_step(p, a.prims, a.n_prims, a.mats, a.n_bounces);
+        if (a.bsdf_model == PT_BSDF_CLASSES) return path_step_alt(p, a.pscene, a.mats, a.n_bounces);
+        return path_step(p, a.pscene, a.mats, a.n_bounces);
     }
     static __device__ __forceinline__ void radiance(const Path& p, float rgb[3]) {
         rgb[0] = p.contrib.x; rgb[1] = p.contrib.y; rgb[2] = p.contrib.z;
@@ -83,12 +83,12 @@ __global__ __launch_bounds__(256) void raypath_kernel(const DPrim* __restrict__ 
     store3(p2, i, pw); store3(n2, i, nw);
 }
 
-__global__ __launch_bounds__(256) void nearest_kernel(const DPrim* __restrict__ prims, int n_prims, const float* __restrict__ o,
+__global__ __launch_bounds__(256) void nearest_kernel(PScene S, const float* __restrict__ o,
                                                       const float* __restrict__ d, int n, int32_t* prim, float* t,
                                                       float* pos, float* nrm, int32_t* inside) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Hit h = nearest_hit(load3(o, i), load3(d, i), prims, n_prims);
+    Hit h = nearest_hit(load3(o, i), load3(d, i), S);
     const bool hit = h.prim >= 0;
     if (prim) prim[i] = h.prim;
     if (t) t[i] = hit ? h.t : 0.0f;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void nearest_kernel(const DPrim* __restrict__ 
     if (inside) inside[i] = hit && h.inside ? 1 : 0;
 }
 
-__global__ __launch_bounds__(256) void trace_parity_kernel(const DPrim* __restrict__ prims, int n_prims, const DMat* __restrict__ mats,
+__global__ __launch_bounds__(256) void trace_parity_kernel(PScene S, const DMat* __restrict__ mats,
                                                            const float* __restrict__ o, const float* __restrict__ d,
                                                            const uint32_t* __restrict__ pixel, const uint32_t* __restrict__ sample,
                                                            int n, uint32_t seed_hash, int n_bounces, int bsdf_model, float* rgb,
@@ -113,8 +113,8 @@ __global__ __launch_bounds__(256) void trace_parity_kernel(const DPrim* __restri
     // assigns none, the last segment of a path that runs out of bounces does.
     for (;;) {
         const V3 o0 = p.o, d0 = p.d;
-        const bool alive = bsdf_model == PT_BSDF_CLASSES ? path_step_alt(p, prims, n_prims, mats, 0x7fffffff)
-                                                         : path_step(p, prims, n_prims, mats, 0x7fffffff);
+        const bool alive = bsdf_model == PT_BSDF_CLASSES ? path_step_alt(p, S, mats, 0x7fffffff)
+                                                         : path_step(p, S, mats, 0x7fffffff);
         if (!alive) { p.o = o0; p.d = d0; break; }
         if (p.seg > n_bounces) break;
     }
@@ -156,7 +156,7 @@ int ptk_raypath_batch(const pt_scene* sc, int prim, const float* o, const float*
 int ptk_nearest_batch(const pt_scene* sc, const float* o, const float* d, int n, int32_t* prim, float* t,
                       float* pos, float* nrm, int32_t* inside, hipStream_t s) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(nearest_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sc->d_prims, sc->n_prims, o, d, n,
+    hipLaunchKernelGGL(nearest_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pt_parity_scene(sc), o, d, n,
                        prim, t, pos, nrm, inside);
     PT_CHECK(hipGetLastError());
     return 0;
@@ -166,7 +166,7 @@ int ptk_trace_paths_parity(const pt_scene* sc, const float* o, const float* d, c
                            const uint32_t* sample, int n, uint32_t seed_hash, int n_bounces, int bsdf_model, float* rgb,
                            float* end_o, float* end_d, hipStream_t s) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(trace_parity_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sc->d_prims, sc->n_prims, sc->d_mats,
+    hipLaunchKernelGGL(trace_parity_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pt_parity_scene(sc), sc->d_mats,
                        o, d, pixel, sample, n, seed_hash, n_bounces, bsdf_model, rgb, end_o, end_d);
     PT_CHECK(hipGetLastError());
     return 0;

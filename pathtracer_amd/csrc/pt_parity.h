@@ -242,23 +242,58 @@ struct Nearest {
     int surf;
 };
 
+// One primitive's part of getNearestIntersection (shapes.h:84-98): its nearest valid intersection replaces the best
+// so far if it is nearer.  In scene order that is the whole rule; TIES adds what makes it independent of the order:
+// of two hits at the same distance the lower scene index wins, which is what the strict '<' gives in scene order.
+template <bool TIES>
+PTD void nearest_consider(Nearest& best, V3 o, V3 d, const DPrim& P, int k) {
+    V3 ol = xpoint(P.inv, o);
+    V3 dl = xvec(P.inv, d);
+    LHit h = shape_local(P.type, ol, dl, P.bounds);
+    eps_filter(h);
+    bool valid; float t; int surf;
+    if (h.n == 1) { valid = h.h1; t = h.t1; surf = h.s1; }
+    else if (h.n == 2) {
+        bool second = h.t2 < h.t1;
+        valid = second ? h.h2 : h.h1; t = second ? h.t2 : h.t1; surf = second ? h.s2 : h.s1;
+    } else { valid = false; t = 0.0f; surf = 0; }
+    if (valid && (best.prim < 0 || t < best.t || (TIES && t == best.t && k < best.prim))) { best.prim = k; best.t = t; best.surf = surf; }
+}
+
 // The loop of getNearestIntersection (shapes.h:79-100): k is wave-uniform, so
 // prims[k] is fetched with scalar loads and the type switch is a scalar branch.
-PTD Nearest nearest_scan(V3 o, V3 d, const DPrim* __restrict__ prims, int n_prims) {
+// A scene with a bounding-volume hierarchy (S.nodes) is searched through it instead: the primitives outside it in
+// that same loop, the others per lane through the skip-link tree, every primitive with the same arithmetic as in the
+// loop.  A box is entered if the ray meets it no later than the best hit so far, boxes are padded beyond the rounding
+// of this test, and ties go to the lower scene index, so the result is the loop's.
+PTD Nearest nearest_scan(V3 o, V3 d, const PScene& S) {
     Nearest best; best.prim = -1; best.t = 0.0f; best.surf = 0;
-    for (int k = 0; k < n_prims; k++) {
-        const DPrim& P = prims[k];
-        V3 ol = xpoint(P.inv, o);
-        V3 dl = xvec(P.inv, d);
-        LHit h = shape_local(P.type, ol, dl, P.bounds);
-        eps_filter(h);
-        bool valid; float t; int surf;
-        if (h.n == 1) { valid = h.h1; t = h.t1; surf = h.s1; }
-        else if (h.n == 2) {
-            bool second = h.t2 < h.t1;
-            valid = second ? h.h2 : h.h1; t = second ? h.t2 : h.t1; surf = second ? h.s2 : h.s1;
-        } else { valid = false; t = 0.0f; surf = 0; }
-        if (valid && (best.prim < 0 || t < best.t)) { best.prim = k; best.t = t; best.surf = surf; }
+    if (S.nodes == nullptr) {
+        for (int k = 0; k < S.n_prims; k++) nearest_consider<false>(best, o, d, S.prims[k], k);
+        return best;
+    }
+    for (int i = 0; i < S.n_top; i++) { const int k = S.top[i]; nearest_consider<false>(best, o, d, S.prims[k], k); }
+    // (a lane without a path carries a zero ray, which no test accepts; it would enter every box that holds the origin)
+    if (d.x == 0.0f && d.y == 0.0f && d.z == 0.0f) return best;
+    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int n = 0;
+    while (n < S.n_nodes) {
+        const BNode& N = S.nodes[n];
+        // slab test; fminf/fmaxf drop a NaN operand (0 * inf when the origin lies on a slab plane of an axis the ray
+        // does not move along), which leaves that axis unconstrained on one side: conservative
+        const float ax = (N.lo[0] - o.x) * inv.x, bx = (N.hi[0] - o.x) * inv.x;
+        const float ay = (N.lo[1] - o.y) * inv.y, by = (N.hi[1] - o.y) * inv.y;
+        const float az = (N.lo[2] - o.z) * inv.z, bz = (N.hi[2] - o.z) * inv.z;
+        const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+        float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        if (best.prim >= 0) tf = fminf(tf, best.t);
+        const bool hit = tn <= tf;
+        const int leaf = N.leaf;
+        if (hit && leaf >= 0) {
+            const BPrim* q = S.bprims + (leaf >> 4);
+            for (int c = leaf & 15; c > 0; c--, q++) { const int k = q->id >> 3; nearest_consider<true>(best, o, d, S.prims[k], k); }
+        }
+        n = (hit && leaf < 0) ? n + 1 : N.skip;
     }
     return best;
 }
@@ -271,8 +306,9 @@ struct Hit {
 };
 
 // getNearestIntersection including the winner's record (shapes.h:93-97).
-PTD Hit nearest_hit(V3 o, V3 d, const DPrim* __restrict__ prims, int n_prims) {
-    Nearest b = nearest_scan(o, d, prims, n_prims);
+PTD Hit nearest_hit(V3 o, V3 d, const PScene& S) {
+    const DPrim* prims = S.prims;
+    Nearest b = nearest_scan(o, d, S);
     Hit h; h.prim = b.prim; h.t = b.t; h.pos = v3(0, 0, 0); h.nrm = v3(0, 0, 0); h.inside = false;
     if (b.prim >= 0) {
         const DPrim& P = prims[b.prim];
@@ -338,8 +374,9 @@ struct Path {
 // One exit and unconditional updates of o, d, coef: a lane whose path ends here is refilled before that state is read
 // again, so it may hold anything, and the old and new state never have to coexist in registers.  A miss goes through
 // the arithmetic with primitive 0's material and is dropped at the end; the arithmetic of a live path is untouched.
-PTD bool path_step(Path& p, const DPrim* __restrict__ prims, int n_prims, const DMat* __restrict__ mats, int n_bounces) {
-    Hit h = nearest_hit(p.o, p.d, prims, n_prims);
+PTD bool path_step(Path& p, const PScene& S, const DMat* __restrict__ mats, int n_bounces) {
+    const DPrim* prims = S.prims;
+    Hit h = nearest_hit(p.o, p.d, S);
     const bool hit = h.prim >= 0;
     const DMat& M = mats[prims[hit ? h.prim : 0].material];
     V3 emissive = v3(M.emissive[0], M.emissive[1], M.emissive[2]);
@@ -411,8 +448,9 @@ PTD void construct_onb(V3 N, V3* x, V3* y) {                                    
 // One iteration of the loop of bsdf_alternative.h:158-217; true = the path goes on.  The switch's `default:` case
 // (:195-199, which leaves the outer variables unset) is taken as Lambertian, and a SmoothDielectric with neither
 // reflection nor transmission (:131-132, `*transmission` unset) as transmission = false.
-PTD bool path_step_alt(Path& p, const DPrim* __restrict__ prims, int n_prims, const DMat* __restrict__ mats, int n_bounces) {
-    Hit h = nearest_hit(p.o, p.d, prims, n_prims);
+PTD bool path_step_alt(Path& p, const PScene& S, const DMat* __restrict__ mats, int n_bounces) {
+    const DPrim* prims = S.prims;
+    Hit h = nearest_hit(p.o, p.d, S);
     if (h.prim < 0) return false;
     const DMat& M = mats[prims[h.prim].material];
     V3 emissive = v3(M.emissive[0], M.emissive[1], M.emissive[2]);

@@ -125,6 +125,15 @@ def _mixed_scene_text(n, walls=True, seed=3):
     return "\n".join(lines) + "\n"
 
 
+def _camera_rays(w, h):
+    """Rays from the origin through a w x h grid on the plane z = -1, as device tensors (origins, directions)."""
+    import torch
+    ys, xs = np.meshgrid(np.linspace(-0.9, 0.9, h), np.linspace(-1.6, 1.6, w), indexing="ij")
+    d = np.stack([xs, ys, -np.ones_like(xs)], axis=-1).reshape(-1, 3)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    return torch.zeros((d.shape[0], 3), device="cuda"), torch.from_numpy(d).cuda()
+
+
 def test_hierarchy_equals_loop_over_all_primitives_bitwise():
     """PT_MATH_FAST searches scenes with many finite primitives through a bounding-volume hierarchy; the nearest
     hit, and so the image, is the one the loop over all primitives (PT_MATH_FAST_SCALAR) finds, bit for bit."""
@@ -155,6 +164,17 @@ def test_hierarchy_equals_loop_over_all_primitives_bitwise():
         if walk:
             sc.tune(pt.binding.PT_TUNE_BVH_WALK, walk)
         assert torch.equal(sc.render(pt.make_config(w, h, spp, n_bounces=depth, math_mode=pt.PT_MATH_FAST)), ref), (options, walk)
+    # the parity-order kernels search the same tree (skip-link form, reference arithmetic at the leaves)
+    sc = pt.Scene(*scene)
+    par_tree = sc.render(pt.make_config(w, h, spp, n_bounces=depth, math_mode=pt.PT_MATH_PARITY))
+    hit_tree = sc.nearest(*_camera_rays(w, h))
+    sc.tune(pt.binding.PT_TUNE_BVH_WALK, 3)
+    par_loop = sc.render(pt.make_config(w, h, spp, n_bounces=depth, math_mode=pt.PT_MATH_PARITY))
+    hit_loop = sc.nearest(*_camera_rays(w, h))
+    assert float(par_tree.sum()) > 0.0 and torch.equal(par_tree, par_loop)
+    assert int((hit_tree["prim"] >= 0).sum()) > 100
+    for name in hit_tree:
+        assert torch.equal(hit_tree[name], hit_loop[name]), name
     # 100 000 primitives: the grid of the node boxes is 16 bits per axis over the whole scene
     sc = pt.Scene(*pt.synthetic_scene(50000, 50000, 99))
     a = sc.render(pt.make_config(96, 54, 2, math_mode=pt.PT_MATH_FAST))

@@ -66,6 +66,23 @@ def test_10k_primitives_hierarchy_equals_loop_at_full_width(torch, pt):
     assert torch.isfinite(full).all() and torch.equal(full[3::90], a)
 
 
+def test_10k_primitives_parity_order_full_frame(torch, pt):
+    """The parity-order kernel searches the hierarchy with the reference's arithmetic at the leaves: the whole
+    10 000-primitive frame (two minutes through its loop) in a fraction of a second, its rows equal to the rows the
+    loop renders, and the fast frame's mean radiance beside it."""
+    sc = pt.Scene(*pt.synthetic_scene(5000, 4989, 12345))
+    full = sc.render(pt.make_config(W, H, SPP, math_mode=pt.PT_MATH_PARITY))
+    assert torch.isfinite(full).all() and float(full.min()) >= 0.0
+    sc.tune(pt.binding.PT_TUNE_BVH_WALK, 3)                    # the loop over all primitives, two rows of it
+    rows = sc.render(pt.make_config(W, H, SPP, row_begin=7, row_step=540, fb_compact=1, math_mode=pt.PT_MATH_PARITY))
+    assert rows.shape[0] == 2 and torch.equal(full[7::540], rows)
+    sc.tune(pt.binding.PT_TUNE_BVH_WALK, 0)
+    fast = sc.render(pt.make_config(W, H, SPP))
+    mf, mp = fast.double().mean(dim=(0, 1)), full.double().mean(dim=(0, 1))
+    print("10 000 primitives 1080p@64: fast / parity mean radiance - 1 per channel", ((mf - mp) / mp).tolist())
+    assert float(((mf - mp).abs() / mp).max()) < tol.FAST["bias_mean_rel_small_shapes"]
+
+
 def test_glass_grid_depth_31_full_frame(torch, pt):
     sc = pt.Scene(*pt.glass_grid_scene(5))
     fast = sc.render(pt.make_config(W, H, SPP, n_bounces=31))
