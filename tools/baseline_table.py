@@ -17,7 +17,7 @@ for r in rows:
         continue
     e = "%.1f" % ex[r["config"]] if (r["mode"] == "fast" and r["config"] in ex) else "—"
     if r["config"] == "5":
-        alg = "— (the hierarchy skips the tests the count charges)" if r["mode"] == "fast" else "%.1f (2 rows: a small launch)" % r["pct_fp32_peak_algorithmic"]
+        alg = "— (the hierarchy skips the tests the count charges)"
     else:
         alg = "%.1f" % r["pct_fp32_peak_algorithmic"]
     print("| %s | %s | %s | MI355X | 1 | %.3f | %.0f | %.1f | %s | %s | %.2e | %.3g | %.2e | %.2e | %d%s |" % (
