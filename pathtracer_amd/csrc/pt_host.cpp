@@ -477,28 +477,30 @@ int bvh_min_levels(int n, int leaf_prims) {
 
 // The fat form of a skip-link tree whose leaves hold one primitive each: one entry per inner node, in the same
 // depth-first order, each with the boxes and references of its two children (left child = next node, right child =
-// the left child's skip link), the boxes on a 16-bit grid over the root's box (origin + step * q; a box only grows).
+// the left child's skip link), the boxes on a 15-bit grid over the root's box (see BFat; `step` is half a grid cell).
 // Returns the depth of the deepest leaf (the root's children are at depth 1): the walk parks at most one reference
 // per level, so this is the stack height a lane can need.
 int build_fat(const std::vector<BNode>& nodes, std::vector<BFat>& fat, float origin[3], float step[3]) {
+    float cell[3];
     for (int k = 0; k < 3; k++) {
         origin[k] = nodes[0].lo[k];
-        step[k] = (nodes[0].hi[k] - nodes[0].lo[k]) / 65535.0f * (1.0f + 1e-6f);
-        if (!(step[k] > 0.0f)) step[k] = 1e-30f;       // a flat box: every coordinate is the origin
+        cell[k] = (nodes[0].hi[k] - nodes[0].lo[k]) / 32767.0f * (1.0f + 1e-6f);
+        if (!(cell[k] > 0.0f)) cell[k] = 1e-30f;       // a flat box: every coordinate is the origin
+        step[k] = 0.5f * cell[k];
     }
-    // the largest q with origin + step * q <= x, and the smallest with origin + step * q >= x, as the float
+    // the largest q with origin + cell * q <= x, and the smallest with origin + cell * q >= x, as the float
     // arithmetic has it
     auto below = [&](float x, int k) {
-        int q = (int)std::floor((x - origin[k]) / step[k]);
-        q = std::min(std::max(q, 0), 65535);
-        while (q > 0 && std::fmaf(step[k], (float)q, origin[k]) > x) q--;
-        return (uint16_t)q;
+        int q = (int)std::floor((x - origin[k]) / cell[k]);
+        q = std::min(std::max(q, 0), 32767);
+        while (q > 0 && std::fmaf(cell[k], (float)q, origin[k]) > x) q--;
+        return q;
     };
     auto above = [&](float x, int k) {
-        int q = (int)std::ceil((x - origin[k]) / step[k]);
-        q = std::min(std::max(q, 0), 65535);
-        while (q < 65535 && std::fmaf(step[k], (float)q, origin[k]) < x) q++;
-        return (uint16_t)q;
+        int q = (int)std::ceil((x - origin[k]) / cell[k]);
+        q = std::min(std::max(q, 0), 32767);
+        while (q < 32767 && std::fmaf(cell[k], (float)q, origin[k]) < x) q++;
+        return q;
     };
     std::vector<int32_t> fat_index(nodes.size(), -1);
     int32_t n_inner = 0;
@@ -511,8 +513,10 @@ int build_fat(const std::vector<BNode>& nodes, std::vector<BFat>& fat, float ori
         BFat& f = fat[(size_t)fat_index[i]];
         std::memset(&f, 0, sizeof(f));
         for (int k = 0; k < 3; k++) {
-            f.lo_a[k] = below(nodes[a].lo[k], k); f.hi_a[k] = above(nodes[a].hi[k], k);
-            f.lo_b[k] = below(nodes[b].lo[k], k); f.hi_b[k] = above(nodes[b].hi[k], k);
+            const int la = below(nodes[a].lo[k], k), ha = std::max(la, above(nodes[a].hi[k], k));
+            const int lb = below(nodes[b].lo[k], k), hb = std::max(lb, above(nodes[b].hi[k], k));
+            f.sum_a[k] = (uint16_t)(la + ha); f.diff_a[k] = (uint16_t)(ha - la);
+            f.sum_b[k] = (uint16_t)(lb + hb); f.diff_b[k] = (uint16_t)(hb - lb);
         }
         f.ref_a = ref_of(a); f.ref_b = ref_of(b);
     }

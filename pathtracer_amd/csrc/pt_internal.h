@@ -104,15 +104,17 @@ struct BPrim {
     int32_t pad[2];
 };
 // The same tree with both children's boxes in the parent, for the ordered walk with a per-lane stack: one visit
-// fetches 32 bytes and decides about two subtrees.  The boxes are 16-bit coordinates on the grid that spans the box
-// of all finite primitives (coordinate = origin + step * q per axis, pt_scene::fat_origin / fat_step; lo rounded
-// down, hi rounded up, so a box only grows): the walk is bound by the vector memory path, and a node of floats would
-// be twice the fetches.  A child reference is an index into this array (>= 0) or, for a one-primitive leaf,
-// ~(index into the BPrim array).  Built when every leaf holds one primitive and the tree has at most 2^19 of them
-// (references are packed into 20 bits on the stack).
+// fetches 32 bytes and decides about two subtrees.  A box is held per axis as the sum and the difference of its two
+// planes' coordinates on the 15-bit grid that spans the box of all finite primitives (plane = origin + step *
+// (sum -+ diff), step = half a grid cell; pt_scene::fat_origin / fat_step; lo rounded down to the grid, hi rounded up,
+// so a box only grows): the walk is bound by the vector memory path and then by instruction issue, a node of floats
+// would be twice the fetches, and from centre and half width the slab distances come as three multiply-adds per
+// axis, without the minimum / maximum that picks the near plane.  A child reference is an index into this array
+// (>= 0) or, for a one-primitive leaf, ~(index into the BPrim array).  Built when every leaf holds one primitive
+// and the tree has at most 2^19 of them (references are packed into 20 bits on the stack).
 struct BFat {
-    uint16_t lo_a[3], hi_a[3];
-    uint16_t lo_b[3], hi_b[3];
+    uint16_t sum_a[3], diff_a[3];
+    uint16_t sum_b[3], diff_b[3];
     int32_t ref_a, ref_b;
 };
 static_assert(sizeof(BFat) == 32, "two 16-byte fetches per node");

@@ -500,8 +500,10 @@ PTD void walk_fat(V3 o, V3 d, float dd, float idd, const BFat* __restrict__ fat,
     // walk stays correct but an axis-parallel ray would descend most of the tree
     const V3 inv = v3(__builtin_amdgcn_fmed3f(rcp(d.x), -1e30f, 1e30f), __builtin_amdgcn_fmed3f(rcp(d.y), -1e30f, 1e30f),
                       __builtin_amdgcn_fmed3f(rcp(d.z), -1e30f, 1e30f));
-    // a box plane at grid coordinate q is met at (origin + step*q - o) * inv = q * ga + gb
+    // a box between the grid coordinates (sum - diff) and (sum + diff) is met from sum * ga + gb - diff * |ga| to
+    // sum * ga + gb + diff * |ga|: (origin + step * q - o) * inv = q * ga + gb
     const V3 ga = step * inv, gb = (origin - o) * inv;
+    const V3 gh = v3(__builtin_fabsf(ga.x), __builtin_fabsf(ga.y), __builtin_fabsf(ga.z));
     for (;;) {
         for (; budget > 0; budget--) {
             budget = __builtin_amdgcn_readfirstlane(budget);
@@ -522,18 +524,18 @@ PTD void walk_fat(V3 o, V3 d, float dd, float idd, const BFat* __restrict__ fat,
                 // does not move along gives 0 * 1e30 = 0: inside that slab)
 #define PT_GRID_LO(w) ((float)((w) & 0xFFFFu))
 #define PT_GRID_HI(w) ((float)((w) >> 16))
-                const float a0x = __builtin_fmaf(PT_GRID_LO(W0.x), ga.x, gb.x), a0y = __builtin_fmaf(PT_GRID_HI(W0.x), ga.y, gb.y);
-                const float a0z = __builtin_fmaf(PT_GRID_LO(W0.y), ga.z, gb.z), a1x = __builtin_fmaf(PT_GRID_HI(W0.y), ga.x, gb.x);
-                const float a1y = __builtin_fmaf(PT_GRID_LO(W0.z), ga.y, gb.y), a1z = __builtin_fmaf(PT_GRID_HI(W0.z), ga.z, gb.z);
-                const float b0x = __builtin_fmaf(PT_GRID_LO(W0.w), ga.x, gb.x), b0y = __builtin_fmaf(PT_GRID_HI(W0.w), ga.y, gb.y);
-                const float b0z = __builtin_fmaf(PT_GRID_LO(W1.x), ga.z, gb.z), b1x = __builtin_fmaf(PT_GRID_HI(W1.x), ga.x, gb.x);
-                const float b1y = __builtin_fmaf(PT_GRID_LO(W1.y), ga.y, gb.y), b1z = __builtin_fmaf(PT_GRID_HI(W1.y), ga.z, gb.z);
+                const float amx = __builtin_fmaf(PT_GRID_LO(W0.x), ga.x, gb.x), amy = __builtin_fmaf(PT_GRID_HI(W0.x), ga.y, gb.y);
+                const float amz = __builtin_fmaf(PT_GRID_LO(W0.y), ga.z, gb.z), ahx = PT_GRID_HI(W0.y) * gh.x;
+                const float ahy = PT_GRID_LO(W0.z) * gh.y, ahz = PT_GRID_HI(W0.z) * gh.z;
+                const float bmx = __builtin_fmaf(PT_GRID_LO(W0.w), ga.x, gb.x), bmy = __builtin_fmaf(PT_GRID_HI(W0.w), ga.y, gb.y);
+                const float bmz = __builtin_fmaf(PT_GRID_LO(W1.x), ga.z, gb.z), bhx = PT_GRID_HI(W1.x) * gh.x;
+                const float bhy = PT_GRID_LO(W1.y) * gh.y, bhz = PT_GRID_HI(W1.y) * gh.z;
 #undef PT_GRID_LO
 #undef PT_GRID_HI
-                const float tna = max3(__builtin_fminf(a0x, a1x), __builtin_fminf(a0y, a1y), __builtin_fmaxf(__builtin_fminf(a0z, a1z), 0.0f));
-                const float tfa = min3(__builtin_fmaxf(a0x, a1x), __builtin_fmaxf(a0y, a1y), __builtin_fminf(__builtin_fmaxf(a0z, a1z), b.t));
-                const float tnb = max3(__builtin_fminf(b0x, b1x), __builtin_fminf(b0y, b1y), __builtin_fmaxf(__builtin_fminf(b0z, b1z), 0.0f));
-                const float tfb = min3(__builtin_fmaxf(b0x, b1x), __builtin_fmaxf(b0y, b1y), __builtin_fminf(__builtin_fmaxf(b0z, b1z), b.t));
+                const float tna = max3(amx - ahx, amy - ahy, __builtin_fmaxf(amz - ahz, 0.0f));
+                const float tfa = min3(amx + ahx, amy + ahy, __builtin_fminf(amz + ahz, b.t));
+                const float tnb = max3(bmx - bhx, bmy - bhy, __builtin_fmaxf(bmz - bhz, 0.0f));
+                const float tfb = min3(bmx + bhx, bmy + bhy, __builtin_fminf(bmz + bhz, b.t));
                 const bool ha = tna <= tfa, hb = tnb <= tfb;
                 const int ra = (int)W1.z, rb = (int)W1.w;
                 const bool a_first = tna <= tnb;
