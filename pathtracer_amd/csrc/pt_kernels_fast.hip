@@ -509,7 +509,7 @@ PTD void walk_fat(V3 o, V3 d, float dd, float idd, const BFat* __restrict__ fat,
             budget = __builtin_amdgcn_readfirstlane(budget);
             if (cur == WALK_NONE && sp != 0) {
                 const uint32_t e = stack[(--sp) * 64];
-                const int ref = (e & 0x80000u) ? ~(int)(e & 0x7FFFFu) : (int)(e & 0x7FFFFu);
+                const int ref = (int)(e << 12) >> 12;       // the low 20 bits, sign-extended: a leaf is ~index
                 cur = __uint_as_float(e & 0xFFF00000u) > b.t ? WALK_NONE : ref;
             }
             const bool inner = (uint32_t)cur < (uint32_t)WALK_NONE;
@@ -542,8 +542,7 @@ PTD void walk_fat(V3 o, V3 d, float dd, float idd, const BFat* __restrict__ fat,
                 const int far = a_first ? rb : ra, near = a_first ? ra : rb;
                 const float tfar = a_first ? tnb : tna;
                 if (ha & hb) {
-                    const uint32_t packed = far < 0 ? (0x80000u | (uint32_t)~far) : (uint32_t)far;
-                    stack[sp * 64] = (__float_as_uint(tfar) & 0xFFF00000u) | packed;
+                    stack[sp * 64] = (__float_as_uint(tfar) & 0xFFF00000u) | ((uint32_t)far & 0xFFFFFu);
                     sp++;
                 }
                 cur = (ha & hb) ? near : (ha ? ra : (hb ? rb : WALK_NONE));
