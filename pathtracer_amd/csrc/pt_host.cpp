@@ -613,6 +613,9 @@ int pt_scene_upload(const pt_prim* prims, int n_prims, const pt_material* mats, 
     return pt_scene_upload_opt(prims, n_prims, mats, n_mats, device, nullptr, out);
 }
 
+static_assert(sizeof(pt_upload_options) == 16 && sizeof(pt_config) == 72 && sizeof(pt_prim) == 72 && sizeof(pt_material) == 72,
+              "the layouts the bindings of other languages assume");
+
 int pt_scene_upload_opt(const pt_prim* prims, int n_prims, const pt_material* mats, int n_mats, int device,
                         const pt_upload_options* opt, pt_scene** out) {
     if (!prims || !mats || !out || n_prims <= 0 || n_mats <= 0) return PT_FAIL("pt_scene_upload: bad arguments");

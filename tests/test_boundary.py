@@ -31,6 +31,7 @@ def test_struct_layouts_match_the_reference_sizes():
     assert C.sizeof(binding.pt_material) == 72          # materials.h: 17 floats + int
     assert C.sizeof(binding.pt_prim) == 72
     assert C.sizeof(binding.pt_config) == 72
+    assert C.sizeof(binding.pt_upload_options) == 16    # four int32 (pt_host.cpp asserts the same of the C struct)
 
 
 def test_default_scene_builder_matches_oracle_bitwise(oracle):
