@@ -884,7 +884,7 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
         // free lanes take entries back from three quarters full (half full: +1.5 %, a quarter: +5 %).
         const uint32_t P = 1u << a.tile_log2;
         const bool tables = sc->n_prims <= 64 && sc->n_mats <= 32;
-        const size_t fixed = 4u * ((size_t)P * 28u + 2816u) + (tables ? (size_t)sc->n_prims * sizeof(FShade) + (size_t)sc->n_mats * sizeof(DMat) : 0u);
+        const size_t fixed = 4u * ((size_t)P * 40u + 2048u) + (tables ? (size_t)sc->n_prims * sizeof(FShade) + (size_t)sc->n_mats * sizeof(DMat) : 0u);
         const size_t budget = 163840u / 6u;
         int cap = fixed < budget ? (int)((budget - fixed) / 256u) & ~3 : 0;
         cap = std::max(16, std::min(40, cap));

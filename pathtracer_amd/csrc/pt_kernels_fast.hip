@@ -44,6 +44,11 @@ struct PhaseClock {
     }
 };
 #define PHASE(clk, i) (clk).mark(i)
+#elif defined(PT_PHASE_MARK)
+// Development aid: the phase boundaries as comments in the compiler's assembly output (tools/isa_phases.py counts the
+// instructions between them).  Not compiled into libpt_hip.so.
+struct PhaseClock { __device__ void start() {} __device__ void mark(int) {} __device__ void flush(unsigned) {} };
+#define PHASE(clk, i) asm volatile("; PHASE " #i)
 #else
 struct PhaseClock { __device__ void start() {} __device__ void mark(int) {} __device__ void flush(unsigned) {} };
 #define PHASE(clk, i) do { } while (0)
@@ -1047,6 +1052,25 @@ template <class T> PTD T* lds_ptr(uint32_t off) { return (T*)(T __attribute__((a
 PTD uint32_t lds_off(const void* p) { return (uint32_t)(uintptr_t)(const void __attribute__((address_space(3)))*)p; }
 PTD uint32_t uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
+// The launch arguments as the kernel finds them in memory (they are its first parameter), behind a pointer the
+// compiler cannot see through.  What the loop with camera batches reads once per tile or once per batch (camera,
+// framebuffer, culling boxes) is read through it where it is used, with scalar loads, instead of living in scalar
+// registers across the whole loop: the loop's own scalars (record offsets and counts, queue counters, masks) then
+// fit the register file without spills to vector lanes.
+#ifndef PT_LAZY_ARGS
+#define PT_LAZY_ARGS 1
+#endif
+typedef const RenderArgs __attribute__((address_space(4)))* KArgsP;
+PTD RenderArgs lazy_args(const RenderArgs& a) {
+#if PT_LAZY_ARGS && defined(__HIP_DEVICE_COMPILE__)   // (the host pass of the compiler only parses this function)
+    KArgsP p = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *p;
+#else
+    return a;
+#endif
+}
+
 struct BatchLds {            // one wave's share of the launch's dynamic LDS
     unsigned long long* acc; // [3*P] pixel sums, 32.32 fixed point
     uint32_t* out_px;        // [P] framebuffer slot of each tile pixel
@@ -1057,16 +1081,16 @@ struct BatchLds {            // one wave's share of the launch's dynamic LDS
 constexpr uint32_t STASH_FLAG = 0x80000000u;
 
 // Dynamic LDS of the launch, in this order: per wave [acc 3*P u64 | gq 4*q_cap float4 | stash 128 float4 |
-// pxt 192 float | out_px P u32], then (LDS_TABLES) the shading records and the materials.
-__host__ __device__ inline size_t batched_wave_bytes(uint32_t P, uint32_t q_cap) { return (size_t)P * 24u + (size_t)q_cap * 64u + 2048u + 768u + (size_t)P * 4u; }
+// pxt 3*P float | out_px P u32], then (LDS_TABLES) the shading records and the materials.
+__host__ __device__ inline size_t batched_wave_bytes(uint32_t P, uint32_t q_cap) { return (size_t)P * 24u + (size_t)q_cap * 64u + 2048u + (size_t)P * 12u + (size_t)P * 4u; }
 // A wave's arrays from the LDS address of its block.
 PTD void carve_wave_lds(uint32_t base, uint32_t P, uint32_t q_cap, BatchLds& L, FastCtx& ctx) {
     L.acc = lds_ptr<unsigned long long>(base);
     L.gq = lds_ptr<float4>(base + P * 24u);
     L.stash = L.gq + 4u * q_cap;
     ctx.pxt = reinterpret_cast<float*>(L.stash + 128);
-    ctx.pxs = 64u;
-    L.out_px = reinterpret_cast<uint32_t*>(ctx.pxt + 192);
+    ctx.pxs = P;
+    L.out_px = reinterpret_cast<uint32_t*>(ctx.pxt + 3u * P);
 }
 
 PTD void add_light(const BatchLds& L, uint32_t px, V3 c, float cap) {
@@ -1227,16 +1251,18 @@ PTD void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds&
     const uint32_t QC = (uint32_t)a.q_cap, QG = (uint32_t)a.q_gate, QI = (uint32_t)a.q_inline;
 
     for (uint32_t k = lane; k < 3u * P; k += 64u) L.acc[k] = 0ull;
-    if (lane < npx) {
-        const ptw::PixelRef ref = ptw::pixel_of(a, lin_base + lane);
-        L.out_px[lane] = ref.out;
-        T::prologue(a, ctx, lane, ref);
-    }
-#ifdef PT_NO_CULL                    // measurement aid: camera rays test every record
-    const unsigned long long cand = ~0ull;
-#else
-    const unsigned long long cand = tile_candidates(a, lin_base, npx, lane);
+    unsigned long long cand = ~0ull;
+    {
+        const RenderArgs la = lazy_args(a);
+        if (lane < npx) {
+            const ptw::PixelRef ref = ptw::pixel_of(la, lin_base + lane);
+            L.out_px[lane] = ref.out;
+            T::prologue(la, ctx, lane, ref);
+        }
+#ifndef PT_NO_CULL                   // (measurement aid: camera rays test every record)
+        cand = tile_candidates(la, lin_base, npx, lane);
 #endif
+    }
 
     ptf::Path path;
     T::idle(path);
@@ -1283,7 +1309,7 @@ PTD void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds&
             for (int pass = 0; pass < 2 && need != 0u; pass++) {
                 if (parked == 0u) {
                     if (made >= total) break;
-                    parked = camera_batch<SORTED, KM>(a, ctx, L, sc, cand, made, total, lin_base, npx, lane);
+                    { const RenderArgs la = lazy_args(a); parked = camera_batch<SORTED, KM>(la, ctx, L, sc, cand, made, total, lin_base, npx, lane); }
 #ifdef PT_BATCH_ONLY                 // measurement aid: camera batches alone (what they park is dropped)
                     parked = 0;
 #endif
@@ -1301,7 +1327,7 @@ PTD void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds&
                     path.contrib = v3(0.0f, 0.0f, 0.0f);
                     if (meta & STASH_FLAG) {
                         ht = A.x; hid = __float_as_int(A.y);
-                        path.o = madd(path.d, ht, v3(a.cam[0], a.cam[1], a.cam[2]));
+                        { const RenderArgs la = lazy_args(a); path.o = madd(path.d, ht, v3(la.cam[0], la.cam[1], la.cam[2])); }
                         path.coef = v3(1.0f, 1.0f, 1.0f);
                         path.seg = 0;
                         camera_hit = true;
@@ -1389,16 +1415,17 @@ PTD void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds&
         PHASE(ctx.clk, 6);
     }
     // p_color = totalLight / n_samples (main.cu:67); consecutive floats of consecutive pixels leave together
-    const float ns = (float)a.n_samples;
-    if (a.fb_layout == PT_FB_AOS) {
+    const RenderArgs le = lazy_args(a);
+    const float ns = (float)le.n_samples;
+    if (le.fb_layout == PT_FB_AOS) {
         for (uint32_t f = lane; f < npx * 3u; f += 64u) {
             const uint32_t px = (f * 43691u) >> 17;          // f / 3 for f < 2^16
-            a.fb[(size_t)L.out_px[px] * 3u + (f - px * 3u)] = ptw::from_fixed(L.acc[f]) / ns;
+            le.fb[(size_t)L.out_px[px] * 3u + (f - px * 3u)] = ptw::from_fixed(L.acc[f]) / ns;
         }
     } else {
-        const size_t plane = a.fb_compact ? (size_t)a.n_lin : (size_t)a.max_x * (size_t)a.max_y;
+        const size_t plane = le.fb_compact ? (size_t)le.n_lin : (size_t)le.max_x * (size_t)le.max_y;
         if (lane < npx)
-            for (int c = 0; c < 3; c++) a.fb[c * plane + L.out_px[lane]] = ptw::from_fixed(L.acc[lane * 3 + c]) / ns;
+            for (int c = 0; c < 3; c++) le.fb[c * plane + L.out_px[lane]] = ptw::from_fixed(L.acc[lane * 3 + c]) / ns;
     }
 }
 
