@@ -647,7 +647,7 @@ int pt_scene_upload_opt(const pt_prim* prims, int n_prims, const pt_material* ma
         aff_store(inv, dp[k].inv);
         aff_store(fwd, dp[k].fwd);
         for (int j = 0; j < 4; j++) dp[k].bounds[j] = prims[k].bounds[j];
-        dp[k].type = prims[k].type; dp[k].material = prims[k].material; dp[k].pad[0] = dp[k].pad[1] = 0;
+        dp[k].type = prims[k].type; dp[k].material = prims[k].material; dp[k].index = k; dp[k].pad = 0;
         std::memset(&baked[k], 0, sizeof(Baked));
         baked[k].len = bake_fast(prims[k], fwd, inv, o.general_kinds, baked[k].rec, &fs[k], &baked[k].kind);
         if (prims[k].type == PT_PLANE) plane_box(prims[k], fwd, baked[k].lo, baked[k].hi);
@@ -655,6 +655,21 @@ int pt_scene_upload_opt(const pt_prim* prims, int n_prims, const pt_material* ma
         all[k] = k;
         (prims[k].type == PT_PLANE ? top : finite).push_back(k);
     }
+    // the parity-order kernels' table sorted by shape type, with the boxes the camera batches cull by (padded like
+    // the hierarchy's boxes: the culling test's rounding must never drop a record its own test accepts)
+    std::vector<DPrim> dp_by_type;
+    std::vector<float> type_boxes;
+    int type_first[5] = {0, 0, 0, 0, 0};
+    for (int t = PT_PLANE; t <= PT_SPHERE; t++) {
+        type_first[t] = (int)dp_by_type.size();
+        for (int k = 0; k < n_prims; k++) {
+            if (dp[k].type != t) continue;
+            dp_by_type.push_back(dp[k]);
+            for (int i = 0; i < 3; i++) type_boxes.push_back(baked[k].lo[i] - 1e-4f * (1.0f + fabsf(baked[k].lo[i])));
+            for (int i = 0; i < 3; i++) type_boxes.push_back(baked[k].hi[i] + 1e-4f * (1.0f + fabsf(baked[k].hi[i])));
+        }
+    }
+    type_first[4] = (int)dp_by_type.size();
     std::vector<float> fdata, fdata_top;
     std::vector<FRun> runs, runs_top;
     std::vector<int32_t> chunk_runs, chunk_runs_top;
@@ -706,6 +721,9 @@ int pt_scene_upload_opt(const pt_prim* prims, int n_prims, const pt_material* ma
     if (e == hipSuccess) e = hipMemcpy(sc->dst, vec.data(), vec.size() * sizeof(T), hipMemcpyHostToDevice); \
     if (e != hipSuccess) { pt_scene_free(sc); return pt_set_error((int)e, "scene upload " #dst, __FILE__, __LINE__); }
     UP(d_prims, dp, DPrim)
+    UP(d_prims_by_type, dp_by_type, DPrim)
+    UP(d_type_box, type_boxes, float)
+    for (int t = 0; t < 5; t++) sc->type_first[t] = type_first[t];
     UP(d_mats, dm, DMat)
     UP(d_fdata, fdata, float)
     UP(d_runs, runs, FRun)
@@ -743,6 +761,8 @@ int pt_scene_free(pt_scene* sc) {
     if (!sc) return 0;
     (void)hipSetDevice(sc->device);
     if (sc->d_prims) (void)hipFree(sc->d_prims);
+    if (sc->d_prims_by_type) (void)hipFree(sc->d_prims_by_type);
+    if (sc->d_type_box) (void)hipFree(sc->d_type_box);
     if (sc->d_mats) (void)hipFree(sc->d_mats);
     if (sc->d_fdata) (void)hipFree(sc->d_fdata);
     if (sc->d_runs) (void)hipFree(sc->d_runs);
@@ -766,6 +786,8 @@ int pt_scene_free(pt_scene* sc) {
 PScene pt_parity_scene(const pt_scene* sc) {
     PScene p;
     p.prims = sc->d_prims; p.n_prims = sc->n_prims;
+    p.by_type = sc->d_prims_by_type; p.boxes = sc->n_prims <= 64 ? sc->d_type_box : nullptr;
+    for (int t = 0; t < 5; t++) p.type_first[t] = sc->type_first[t];
     p.nodes = sc->d_bnodes; p.n_nodes = sc->n_bnodes; p.bprims = sc->d_bprims;
     p.top = sc->d_top_ids; p.n_top = sc->n_top_ids;
     if (sc->tune[PT_TUNE_BVH_WALK] == 3) { p.nodes = nullptr; p.n_nodes = 0; }    // the loop over all primitives is asked for
@@ -844,8 +866,11 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     // fixed-point sums).
     // The loop with camera batches keeps 32 up to the largest frames (3840x2160 @ 1024: 181 ms against 202 with 64) and
     // takes it from 0.9 Mpixel (half a 1080p frame: 1.479 ms against 1.508 with 16; a third: 1.040 against 1.024).
-    const bool batched = cfg->math_mode == PT_MATH_FAST && cfg->bsdf_model == PT_BSDF_REFERENCE && sc->n_bnodes == 0 &&
-                         sc->tune[PT_TUNE_GLASS_QUEUE] >= 0;
+    // (the loop with camera batches and the queue of set-aside hits shades with bsdf.h's tracePath only and searches
+    // no hierarchy; the class-based model and scenes with a hierarchy keep the plain loop)
+    const bool fast_batched = cfg->math_mode == PT_MATH_FAST && sc->n_bnodes == 0;
+    const bool parity_batched = cfg->math_mode == PT_MATH_PARITY && (sc->n_bnodes == 0 || sc->tune[PT_TUNE_BVH_WALK] == 3);
+    const bool batched = (fast_batched || parity_batched) && cfg->bsdf_model == PT_BSDF_REFERENCE && sc->tune[PT_TUNE_GLASS_QUEUE] >= 0;
     a.tile_log2 = (a.n_lin >= 6000000u && !batched) ? 6 : (a.n_lin >= (batched ? 900000u : 1500000u) ? 5 : (a.n_lin >= 200000u ? 4 : 3));
     // ... and a pool of at least ~2048 samples per wave, or the drain phase dominates at low sample counts (10 000
     // primitives, 1080p, 4 spp: 263 ms with 32 pixels per wave, 216 ms with 64) — as long as that leaves two waves
@@ -876,18 +901,20 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
         if (sc->tune[PT_TUNE_WALK_BUDGET] != 0) a.walk_budget = sc->tune[PT_TUNE_WALK_BUDGET];
         if (sc->tune[PT_TUNE_SHADE_GATE] != 0) a.shade_gate = sc->tune[PT_TUNE_SHADE_GATE];
     } else if (batched) {
-        // (the loop with camera batches and the glass queue shades with bsdf.h's tracePath only; the class-based model
-        // keeps the plain loop)
         // The queue of set-aside glass hits: as many entries as fit beside the per-wave arrays and the tables while
         // six workgroups still share a compute unit's 160 KiB of LDS.  Measured on the 1080p frame of the default scene
         // (tools/q_sweep.py): 40 entries at six workgroups 3.12 ms, 24 entries at seven 3.19, 48 entries at five 3.37;
         // free lanes take entries back from three quarters full (half full: +1.5 %, a quarter: +5 %).
         const uint32_t P = 1u << a.tile_log2;
         const bool tables = sc->n_prims <= 64 && sc->n_mats <= 32;
-        const size_t fixed = 4u * ((size_t)P * 40u + 2048u) + (tables ? (size_t)sc->n_prims * sizeof(FShade) + (size_t)sc->n_mats * sizeof(DMat) : 0u);
+        const size_t table_bytes = parity_batched ? (sc->n_mats <= 32 ? (size_t)sc->n_mats * sizeof(DMat) : 0u)
+                                                  : (tables ? (size_t)sc->n_prims * sizeof(FShade) + (size_t)sc->n_mats * sizeof(DMat) : 0u);
+        const size_t fixed = 4u * ((size_t)P * 40u + 2048u) + table_bytes;
         const size_t budget = 163840u / 6u;
         int cap = fixed < budget ? (int)((budget - fixed) / 256u) & ~3 : 0;
-        cap = std::max(16, std::min(40, cap));
+        // (the parity-order loop, whose full shading is several times the fast one's, gains a little from a longer queue:
+        // 1080p frame 7.70 ms with 40 entries, 7.61 with 48, 7.81 with 56 at five workgroups)
+        cap = std::max(16, std::min(parity_batched ? 48 : 40, cap));
         if (sc->tune[PT_TUNE_GLASS_QUEUE] != 0) cap = sc->tune[PT_TUNE_GLASS_QUEUE];
         int gate = (3 * cap) / 4;
         if (sc->tune[PT_TUNE_GLASS_GATE] != 0) gate = std::min(sc->tune[PT_TUNE_GLASS_GATE], cap);

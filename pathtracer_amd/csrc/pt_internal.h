@@ -16,7 +16,8 @@ struct DPrim {
     float bounds[4];  // Plane xMin, yMin, xMax, yMax (shapes.h:105-109)
     int32_t type;
     int32_t material;
-    int32_t pad[2];
+    int32_t index;    // the primitive's index in the scene (the copies sorted by type need it; in scene order it is the position)
+    int32_t pad;
 };
 
 // Material padded to 80 bytes so a lane can fetch it with five 16-byte reads.
@@ -135,6 +136,13 @@ constexpr int BVH_LEAF_PRIMS = 1;     // measured on the 10 000-primitive scene:
 struct PScene {
     const DPrim* prims;
     int32_t n_prims;
+    // The same records sorted by shape type (PT_PLANE, PT_CUBE, PT_CYLINDER, PT_SPHERE; scene order within a type):
+    // records [type_first[t], type_first[t + 1]) are of type t.  The loop with camera batches runs one typed loop per
+    // shape type over them, which the (distance, scene index) rule allows.  `boxes` holds a padded world-space box
+    // (lo.xyz, hi.xyz) per record of `by_type`, for the per-tile culling of camera rays, or is null.
+    const DPrim* by_type;
+    int32_t type_first[5];
+    const float* boxes;
     const BNode* nodes;
     int32_t n_nodes;
     const BPrim* bprims;
@@ -147,6 +155,9 @@ struct pt_scene {
     int n_prims;
     int n_mats;
     DPrim* d_prims;
+    DPrim* d_prims_by_type;                // the same sorted by shape type, and a world-space box for each of them
+    int type_first[5];
+    float* d_type_box;
     DMat* d_mats;
     float* d_fdata;        // fast-kernel intersection records
     FRun* d_runs;

@@ -20,6 +20,7 @@
 // Results differ from the parity-order kernels by rounding only.
 #include "pt_internal.h"
 #include "pt_wavepool.h"
+#include "pt_batched.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -1022,131 +1023,8 @@ struct FastTracer {
 };
 
 
-// ---- PT_MATH_FAST without a hierarchy: camera rays in batches, glass hits set aside ------------------------------
-//
-// The plain loop (render_tile) treats every segment alike: each iteration tests all primitives for all 64 lanes and
-// runs the whole of shade_scatter.  Two things are different here.
-//
-// Camera rays in batches.  The first segment of 64 samples is traced by all 64 lanes at once (camera_batch): rays
-// are made, tested and shaded together, and what continues is parked in LDS as a secondary ray of 32 bytes (origin,
-// RNG key | direction, pixel and material) for a lane of the main loop to pick up; paths that end at their first hit
-// add their light to the pixel at once.  The rays of a batch leave one point towards a few adjacent pixels, so most
-// of the scene cannot be hit by any of them: once per tile, lane l tests the box of record l against the tile's view
-// pyramid (tile_candidates) and the ballot of the survivors is the list of records the batches test.  The main loop
-// is then left with secondary segments only.
-//
-// Glass hits set aside.  In the plain loop every iteration runs Beer term, Fresnel ratio, mode draw, reflected and
-// refracted directions for the few lanes whose hit needs them (7 % of the hits of the default scene), at the price
-// of a full wave each time.  Here the loop body shades the common case only (shade_diffuse).  A lane whose hit
-// needs more writes its path and hit to a small queue in LDS and is free for new work at once; when enough have
-// gathered (q_gate), free lanes take them back and shade_scatter runs for all of them together.  If many lanes need
-// it in the same iteration (q_inline or more: a wave looking at glass) they keep their state in registers instead and
-// are shaded at the same place one iteration later; camera rays that hit glass are parked with their hit and join
-// them.  The queue never holds more than (q_gate - 1) + (q_inline - 1) <= q_cap entries: after the take-back step
-// it is below q_gate (it takes whenever it holds q_gate or more, and the lanes that put entries in are free by
-// then), and fewer than q_inline are put in per iteration.
-//
-// Arithmetic per path is the plain loop's, and pixel sums do not depend on the order of the additions, so the image
-// is the plain loop's bit for bit (PT_MATH_FAST_SCALAR keeps the plain loop; tested).
-template <class T> PTD T* lds_ptr(uint32_t off) { return (T*)(T __attribute__((address_space(3)))*)(uintptr_t)off; }
-PTD uint32_t lds_off(const void* p) { return (uint32_t)(uintptr_t)(const void __attribute__((address_space(3)))*)p; }
-PTD uint32_t uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
-
-// The launch arguments as the kernel finds them in memory (they are its first parameter), behind a pointer the
-// compiler cannot see through.  What the loop with camera batches reads once per tile or once per batch (camera,
-// framebuffer, culling boxes) is read through it where it is used, with scalar loads, instead of living in scalar
-// registers across the whole loop: the loop's own scalars (record offsets and counts, queue counters, masks) then
-// fit the register file without spills to vector lanes.
-#ifndef PT_LAZY_ARGS
-#define PT_LAZY_ARGS 1
-#endif
-typedef const RenderArgs __attribute__((address_space(4)))* KArgsP;
-PTD RenderArgs lazy_args(const RenderArgs& a) {
-#if PT_LAZY_ARGS && defined(__HIP_DEVICE_COMPILE__)   // (the host pass of the compiler only parses this function)
-    KArgsP p = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
-    return *p;
-#else
-    return a;
-#endif
-}
-
-struct BatchLds {            // one wave's share of the launch's dynamic LDS
-    unsigned long long* acc; // [3*P] pixel sums, 32.32 fixed point
-    uint32_t* out_px;        // [P] framebuffer slot of each tile pixel
-    float4* stash;           // [2][64] parked work: secondary ray (origin, key | direction, pixel | material << 8), or a
-                             // camera ray with a hit that needs shade_scatter (t, id, -, key | direction, pixel | 1 << 31)
-    float4* gq;              // [4][q_cap] set-aside hits: (pos, t) | (d, id) | (coef, key) | (contrib, seg << 8 | pixel)
-};
-constexpr uint32_t STASH_FLAG = 0x80000000u;
-
-// Dynamic LDS of the launch, in this order: per wave [acc 3*P u64 | gq 4*q_cap float4 | stash 128 float4 |
-// pxt 3*P float | out_px P u32], then (LDS_TABLES) the shading records and the materials.
-__host__ __device__ inline size_t batched_wave_bytes(uint32_t P, uint32_t q_cap) { return (size_t)P * 24u + (size_t)q_cap * 64u + 2048u + (size_t)P * 12u + (size_t)P * 4u; }
-// A wave's arrays from the LDS address of its block.
-PTD void carve_wave_lds(uint32_t base, uint32_t P, uint32_t q_cap, BatchLds& L, FastCtx& ctx) {
-    L.acc = lds_ptr<unsigned long long>(base);
-    L.gq = lds_ptr<float4>(base + P * 24u);
-    L.stash = L.gq + 4u * q_cap;
-    ctx.pxt = reinterpret_cast<float*>(L.stash + 128);
-    ctx.pxs = P;
-    L.out_px = reinterpret_cast<uint32_t*>(ctx.pxt + 3u * P);
-}
-
-PTD void add_light(const BatchLds& L, uint32_t px, V3 c, float cap) {
-    // most paths end without having met a light: a zero adds nothing to a fixed-point sum (nor does a negative zero)
-    if (c.x == 0.0f && c.y == 0.0f && c.z == 0.0f) return;
-    // one test for "some channel is a NaN or beyond the cap" (the compare is false for a NaN); the clamp itself
-    // (ptw::to_fixed) then only runs for such samples
-    if (!(max3(__builtin_fabsf(c.x), __builtin_fabsf(c.y), __builtin_fabsf(c.z)) <= cap) || c.x != c.x || c.y != c.y || c.z != c.z) {
-        __hip_atomic_fetch_add(&L.acc[px * 3u], ptw::to_fixed(c.x, cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        __hip_atomic_fetch_add(&L.acc[px * 3u + 1u], ptw::to_fixed(c.y, cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        __hip_atomic_fetch_add(&L.acc[px * 3u + 2u], ptw::to_fixed(c.z, cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        return;
-    }
-    __hip_atomic_fetch_add(&L.acc[px * 3u], ptw::to_fixed_in_range(c.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    __hip_atomic_fetch_add(&L.acc[px * 3u + 1u], ptw::to_fixed_in_range(c.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    __hip_atomic_fetch_add(&L.acc[px * 3u + 2u], ptw::to_fixed_in_range(c.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-}
-
-// Which records of the kind-sorted table can a camera ray of this tile hit?  Bit s = record s (records are numbered
-// through the kinds in FP_* order).  Camera rays are cam + t * (X, Y, Z0) with Z0 = p00.z - cam.z and (X, Y) inside
-// the rectangle the tile's pixels span on the sample plane (main.cu:40-63; jitter included, one pixel of margin).
-// Lane s projects box s onto that plane, clipped to the half space in front of the camera, by interval arithmetic;
-// a box whose projection misses the rectangle is dropped.  Anything undecidable (NaN from inf/inf, a box around the
-// camera) fails the "misses" compare and stays in.
-PTD unsigned long long tile_candidates(const RenderArgs& a, uint32_t lin_base, uint32_t npx, unsigned lane) {
-    if (a.slot_box == nullptr || a.n_slots > 64) return ~0ull;
-    const uint32_t W = (uint32_t)a.max_x;
-    const uint32_t k0 = lin_base / W, k1 = (lin_base + npx - 1u) / W;
-    const uint32_t i0 = k0 == k1 ? lin_base - k0 * W : 0u, i1 = k0 == k1 ? lin_base + npx - 1u - k0 * W : W - 1u;
-    const int j0 = a.row_begin + (int)k0 * a.row_step, j1 = a.row_begin + (int)k1 * a.row_step;
-    // sample-plane coordinates (main.cu:62): sx = i - 0.5 + U, sy = max_y - j - 0.5 + U, U in (0,1]
-    const float sx0 = (float)i0 - 1.5f, sx1 = (float)i1 + 1.5f;
-    const float sy0 = (float)(a.max_y - max(j0, j1)) - 1.5f, sy1 = (float)(a.max_y - min(j0, j1)) + 1.5f;
-    const float xa = a.du * sx0 + (a.p00[0] - a.cam[0]), xb = a.du * sx1 + (a.p00[0] - a.cam[0]);
-    const float ya = a.dv * sy0 + (a.p00[1] - a.cam[1]), yb = a.dv * sy1 + (a.p00[1] - a.cam[1]);
-    const float X0 = __builtin_fminf(xa, xb), X1 = __builtin_fmaxf(xa, xb), Y0 = __builtin_fminf(ya, yb), Y1 = __builtin_fmaxf(ya, yb);
-    const float Z0 = a.p00[2] - a.cam[2];
-    bool keep = false;
-    if ((int)lane < a.n_slots) {
-        const float* B = a.slot_box + 6 * lane;
-        const float lx = B[0] - a.cam[0], ly = B[1] - a.cam[1], lz = B[2] - a.cam[2];
-        const float hx = B[3] - a.cam[0], hy = B[4] - a.cam[1], hz = B[5] - a.cam[2];
-        // ray parameter t = z / Z0 over the box; only t > 0 is in front of the camera
-        const float ta = lz / Z0, tb = hz / Z0;
-        const float t_hi = __builtin_fmaxf(ta, tb);
-        const float t_lo = __builtin_fmaxf(__builtin_fminf(ta, tb), 1e-30f);
-        const float slack = 1e-4f;
-        // projection x / t over x in [lx, hx], t in [t_lo, t_hi] (t > 0): lowest from lx, highest from hx
-        const float px_lo = __builtin_fminf(lx / t_lo, lx / t_hi), px_hi = __builtin_fmaxf(hx / t_lo, hx / t_hi);
-        const float py_lo = __builtin_fminf(ly / t_lo, ly / t_hi), py_hi = __builtin_fmaxf(hy / t_lo, hy / t_hi);
-        const float mx = slack * (__builtin_fabsf(X0) + __builtin_fabsf(X1)), my = slack * (__builtin_fabsf(Y0) + __builtin_fabsf(Y1));
-        const bool misses = (t_hi <= 0.0f) || (px_hi < X0 - mx) || (px_lo > X1 + mx) || (py_hi < Y0 - my) || (py_lo > Y1 + my);
-        keep = !misses;
-    }
-    return __ballot(keep);
-}
+// ---- PT_MATH_FAST without a hierarchy: camera rays in batches, hits that need the full shading set aside ---------
+// (the loop itself is pt_batched.h's; this is the fast arithmetic it runs on)
 
 // scan_sorted over the records whose bit is set in `mask` (bit s = record s, numbered through the kinds in FP_*
 // order, which is the order of this function).  Same tests, same (distance, index) rule: the result is scan_sorted's
@@ -1182,258 +1060,63 @@ PTD void scan_sorted_masked(V3 o, V3 d, float dd, float idd, const FSorted& S0, 
 #undef PT_KIND_LOOP
 }
 
-// The first segment of pool items made .. made + 63, one per lane: camera ray (main.cu:62-64), nearest hit among the
-// tile's candidate records, surface, emissive term and — for a hit that shade_diffuse covers — new direction and
-// roulette.  What goes on is parked in L.stash, packed from entry 0; returns the number of entries.
+// The fast kernels' arithmetic for the loop of pt_batched.h.  A set-aside hit keeps its position (the surface record
+// needs nothing else of the ray).
 template <bool SORTED, int KM>
-PTD uint32_t camera_batch(const RenderArgs& a, FastCtx& ctx, const BatchLds& L, const SceneRefs& sc, unsigned long long cand,
-                          uint32_t made, uint32_t total, uint32_t lin_base, uint32_t npx, unsigned lane) {
+struct FastBatched {
+    using V3 = ptf::V3;
+    using Path = ptf::Path;
+    using Best = ptf::Best;
+    using Surf = ptf::Surf;
+    using Ctx = FastCtx;
+    using Scene = SceneRefs;
     using T = FastTracer<0, SORTED>;
-    const uint32_t lg = (uint32_t)a.tile_log2, P = 1u << lg;
-    const uint32_t w = made + lane;
-    const uint32_t px = w & (P - 1u);
-    const bool valid = w < total && px < npx;
-    float4 ray;
-    T::make_ray(a, ctx, px, lin_base + px, w >> lg, ray);
-    const V3 o = v3(a.cam[0], a.cam[1], a.cam[2]), d = v3(ray.x, ray.y, ray.z);
-    const uint32_t key = __float_as_uint(ray.w);
-    Best b0 = best_none();
-    {
+    static PTD V3 v3(float x, float y, float z) { return ptf::v3(x, y, z); }
+    static PTD Scene scene(const RenderArgs& a) {
+        SceneRefs sc;
+        sc.fdata = a.fdata; sc.runs = a.runs; sc.n_runs = a.n_runs;
+        sc.nodes = nullptr; sc.bprims = nullptr; sc.n_nodes = 0; sc.fat = nullptr; sc.sorted = a.sorted;
+        return sc;
+    }
+    static PTD void prologue(const RenderArgs& a, Ctx& c, uint32_t px, const ptw::PixelRef& ref) { T::prologue(a, c, px, ref); }
+    static PTD void make_ray(const RenderArgs& a, Ctx& c, uint32_t px, uint32_t sample, float4& ray) { T::make_ray(a, c, px, 0u, sample, ray); }
+    static PTD const float* cull_boxes(const RenderArgs& a, int& n) { n = a.n_slots; return a.slot_box; }
+    static PTD Best scan(V3 o, V3 d, const Scene& sc) {
+        Best b = best_none();
+        const float dd = dot(d, d), idd = rcp(dd);
+        if (SORTED) scan_sorted<KM>(o, d, dd, idd, sc.sorted, b);
+        else scan_runs(o, d, dd, idd, as_constant(sc.fdata), as_constant(sc.runs), 0, sc.n_runs, b);
+        return b;
+    }
+    static PTD Best scan_camera(V3 o, V3 d, const Scene& sc, const RenderArgs& a, unsigned long long cand) {
+        Best b = best_none();
         const float dd = dot(d, d), idd = rcp(dd);
         if (SORTED) {
-            if (a.slot_box != nullptr && a.n_slots <= 64) scan_sorted_masked<KM>(o, d, dd, idd, sc.sorted, cand, b0);
-            else scan_sorted<KM>(o, d, dd, idd, sc.sorted, b0);
+            if (a.slot_box != nullptr && a.n_slots <= 64) scan_sorted_masked<KM>(o, d, dd, idd, sc.sorted, cand, b);
+            else scan_sorted<KM>(o, d, dd, idd, sc.sorted, b);
         } else {
-            scan_runs(o, d, dd, idd, as_constant(sc.fdata), as_constant(sc.runs), 0, sc.n_runs, b0);
+            scan_runs(o, d, dd, idd, as_constant(sc.fdata), as_constant(sc.runs), 0, sc.n_runs, b);
         }
+        return b;
     }
-    const bool hit = valid && b0.id >= 0;
-    Best b = b0;
-    b.id = hit ? b0.id : 0;
-    const Surf s = surface(b, o, d, ctx.shade);
-    const DMat& M = ctx.mats[s.material];
-    // the path so far: coefficient 1, no light; shade_emissive and shade_diffuse as the main loop runs them
-    ptf::Path p;
-    p.o = o; p.d = d; p.coef = v3(1.0f, 1.0f, 1.0f); p.contrib = v3(0.0f, 0.0f, 0.0f); p.key = key; p.seg = 0;
-    shade_emissive(p, hit, M);
-    const bool lit = (p.contrib.x != 0.0f) || (p.contrib.y != 0.0f) || (p.contrib.z != 0.0f);
-    const float m_f0 = M.f0, m_tr = M.transparency;
-    const bool special = hit & ((m_f0 != 0.0f) | (m_tr != 0.0f));
-    const V3 light = p.contrib;
-    const bool go_on = shade_diffuse(p, s, M, hit, false, a.n_bounces);
-    // a secondary ray carries no light of its own: a hit that is lit and goes on keeps its camera ray and is shaded
-    // again from its hit, with the hits that need shade_scatter anyway
-    const bool as_hit = special || (hit && go_on && lit);
-    const bool as_ray = hit && go_on && !as_hit;
-    if (hit && !as_hit && !go_on && lit) add_light(L, px, light, a.sample_cap);
-    const unsigned long long park = __ballot(as_hit || as_ray);
-    const uint32_t e = ptw::prefix_count(park);
-    if (as_ray) {
-        L.stash[e] = make_float4(p.o.x, p.o.y, p.o.z, __uint_as_float(key));
-        L.stash[64u + e] = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(px | ((uint32_t)s.material << 8)));
-    }
-    if (as_hit) {
-        L.stash[e] = make_float4(b.t, __int_as_float(b.id), 0.0f, __uint_as_float(key));
-        L.stash[64u + e] = make_float4(d.x, d.y, d.z, __uint_as_float(px | STASH_FLAG));
-    }
-    return (uint32_t)__popcll(park);
-}
-
-template <bool LDS_TABLES, bool SORTED, int KM>
-PTD void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds& L, FastCtx& ctx) {
-    using T = FastTracer<0, SORTED>;
-    enum { FREE = 0, ACTIVE = 1, GLASS = 2 };
-    const unsigned lane = ptw::lane_id();
-    const uint32_t lg = (uint32_t)a.tile_log2, P = 1u << lg;
-    const uint32_t lin_base = tile << lg;
-    const uint32_t npx = min(P, a.n_lin - lin_base);
-    const uint32_t total = (uint32_t)a.n_samples << lg;
-    const uint32_t QC = (uint32_t)a.q_cap, QG = (uint32_t)a.q_gate, QI = (uint32_t)a.q_inline;
-
-    for (uint32_t k = lane; k < 3u * P; k += 64u) L.acc[k] = 0ull;
-    unsigned long long cand = ~0ull;
-    {
-        const RenderArgs la = lazy_args(a);
-        if (lane < npx) {
-            const ptw::PixelRef ref = ptw::pixel_of(la, lin_base + lane);
-            L.out_px[lane] = ref.out;
-            T::prologue(la, ctx, lane, ref);
-        }
-#ifndef PT_NO_CULL                   // (measurement aid: camera rays test every record)
-        cand = tile_candidates(la, lin_base, npx, lane);
-#endif
-    }
-
-    ptf::Path path;
-    T::idle(path);
-    uint32_t my_px = 0;
-    int st = FREE;
-    float ht = 0.0f;                 // a GLASS lane's hit: distance and code; its position is path.o
-    int hid = 0;
-    bool camera_hit = false;         // ... and whether it is a camera ray's, whose emissive term is still to be added
-    uint32_t made = 0;               // wave-uniform: pool items the batches have traced
-    uint32_t parked = 0;             // wave-uniform: entries in the stash
-    uint32_t qn = 0;                 // wave-uniform: entries in the queue
-    SceneRefs sc;
-    sc.fdata = a.fdata; sc.runs = a.runs; sc.n_runs = a.n_runs;
-    sc.nodes = nullptr; sc.bprims = nullptr; sc.n_nodes = 0; sc.fat = nullptr; sc.sorted = a.sorted;
-    for (;;) {
-        // wave-uniform by construction; said once per iteration so that the compiler keeps them in scalar registers
-        made = uniform(made); parked = uniform(parked); qn = uniform(qn);
-        // 1. free lanes take set-aside hits back
-        unsigned long long want = __ballot(st == FREE);
-        if (want != 0ull && qn != 0u && (qn >= QG || __ballot(st == GLASS) != 0ull || (made >= total && parked == 0u))) {
-            const uint32_t rank = ptw::prefix_count(want);
-            const uint32_t take = min((uint32_t)__popcll(want), qn);
-            if (st == FREE && rank < take) {
-                const uint32_t e = qn - 1u - rank;
-                const float4 r0 = L.gq[e], r1 = L.gq[QC + e], r2 = L.gq[2u * QC + e], r3 = L.gq[3u * QC + e];
-                path.o = v3(r0.x, r0.y, r0.z); ht = r0.w;
-                path.d = v3(r1.x, r1.y, r1.z); hid = __float_as_int(r1.w);
-                path.coef = v3(r2.x, r2.y, r2.z); path.key = __float_as_uint(r2.w);
-                path.contrib = v3(r3.x, r3.y, r3.z);
-                const uint32_t sp = __float_as_uint(r3.w);
-                path.seg = (int)(sp >> 8); my_px = sp & 255u;
-                camera_hit = false;
-                st = GLASS;
-            }
-            qn -= take;
-            want = __ballot(st == FREE);
-        }
-        // 2. parked work for the lanes that are still free: what is parked, then a camera batch if that was not
-        //    enough, then what the batch parked (lanes it cannot serve wait one iteration)
-        uint32_t need = (uint32_t)__popcll(want);
-        if (need != 0u) {
-            const uint32_t rank = ptw::prefix_count(want);
-            uint32_t served = 0;
-            for (int pass = 0; pass < 2 && need != 0u; pass++) {
-                if (parked == 0u) {
-                    if (made >= total) break;
-                    { const RenderArgs la = lazy_args(a); parked = camera_batch<SORTED, KM>(la, ctx, L, sc, cand, made, total, lin_base, npx, lane); }
-#ifdef PT_BATCH_ONLY                 // measurement aid: camera batches alone (what they park is dropped)
-                    parked = 0;
-#endif
-                    made = min(made + 64u, total);
-                    PHASE(ctx.clk, 7);
-                }
-                const uint32_t take = min(need, parked);
-                if (st == FREE && rank >= served && rank < served + take) {
-                    const uint32_t e = parked - 1u - (rank - served);
-                    const float4 A = L.stash[e], B = L.stash[64u + e];
-                    const uint32_t meta = __float_as_uint(B.w);
-                    my_px = meta & 255u;
-                    path.d = v3(B.x, B.y, B.z);
-                    path.key = __float_as_uint(A.w);
-                    path.contrib = v3(0.0f, 0.0f, 0.0f);
-                    if (meta & STASH_FLAG) {
-                        ht = A.x; hid = __float_as_int(A.y);
-                        { const RenderArgs la = lazy_args(a); path.o = madd(path.d, ht, v3(la.cam[0], la.cam[1], la.cam[2])); }
-                        path.coef = v3(1.0f, 1.0f, 1.0f);
-                        path.seg = 0;
-                        camera_hit = true;
-                        st = GLASS;
-                    } else {
-                        // throughput after the first hit, as shade_diffuse left it: albedo / max(albedo)
-                        const DMat& M = ctx.mats[(meta & ~STASH_FLAG) >> 8];
-                        const V3 alb = v3(M.albedo[0], M.albedo[1], M.albedo[2]);
-                        path.o = v3(A.x, A.y, A.z);
-                        path.coef = alb * rcp(max3(alb.x, alb.y, alb.z));
-                        path.seg = 1;
-                        st = ACTIVE;
-                    }
-                }
-                parked -= take; served += take; need -= take;
-            }
-        }
-        PHASE(ctx.clk, 0);
-        // 3. the full shading for the lanes that hold a hit which needs it
-        if (__ballot(st == GLASS) != 0ull) {
-            if (st == GLASS) {
-                Best b; b.t = ht; b.id = hid;
-                const Surf s = surface_at(b, path.o, path.d, ctx.shade);
-                const DMat& M = ctx.mats[s.material];
-                shade_emissive(path, camera_hit, M);
-                const bool go_on = shade_scatter(path, s, M, ht, true, a.n_bounces, ctx.clk);
-                st = ACTIVE;
-                if (!go_on) {
-                    add_light(L, my_px, path.contrib, a.sample_cap);
-                    st = FREE;
-                }
-            }
-        }
-        PHASE(ctx.clk, 3);
-        if (__ballot(st != FREE) == 0ull) {
-            if (made >= total && parked == 0u && qn == 0u) break;
-            continue;
-        }
-        // 4. one segment for every lane (a free lane steps whatever state it holds; the result is dropped)
-        Best b0 = best_none();
-        {
-            const float dd = dot(path.d, path.d), idd = rcp(dd);
-            if (SORTED) scan_sorted<KM>(path.o, path.d, dd, idd, sc.sorted, b0);
-            else scan_runs(path.o, path.d, dd, idd, as_constant(sc.fdata), as_constant(sc.runs), 0, sc.n_runs, b0);
-        }
-        PHASE(ctx.clk, 1);
-        const bool hit = b0.id >= 0;
-        Best b = b0;
-        b.id = hit ? b0.id : 0;                        // a miss reads primitive 0's records and is dropped below
-        const Surf s = surface(b, path.o, path.d, ctx.shade);
-        const DMat& M = ctx.mats[s.material];
-        PHASE(ctx.clk, 2);
-        shade_emissive(path, hit, M);
-        // (plain & and |: both material fields are fetched at once instead of one behind a branch on the other)
-        const float m_f0 = M.f0, m_tr = M.transparency;
-        const bool special = hit & (st == ACTIVE) & ((m_f0 != 0.0f) | (m_tr != 0.0f) | ((path.seg > 0) & s.inside));
-        // 5. hits that need the full shading: into the queue (the lane is free at once), or kept in registers
-        const unsigned long long special_m = __ballot(special);
-        bool keep = false;
-        if (special_m != 0ull) {
-            const uint32_t g = (uint32_t)__popcll(special_m);
-            if (g >= QI || qn + g > QC) {
-                keep = special;
-            } else {
-                if (special) {
-                    const uint32_t e = qn + ptw::prefix_count(special_m);
-                    L.gq[e] = make_float4(s.pos.x, s.pos.y, s.pos.z, b.t);
-                    L.gq[QC + e] = make_float4(path.d.x, path.d.y, path.d.z, __int_as_float(b.id));
-                    L.gq[2u * QC + e] = make_float4(path.coef.x, path.coef.y, path.coef.z, __uint_as_float(path.key));
-                    L.gq[3u * QC + e] = make_float4(path.contrib.x, path.contrib.y, path.contrib.z, __uint_as_float(((uint32_t)path.seg << 8) | my_px));
-                    st = FREE;
-                }
-                qn += g;
-            }
-        }
-        if (keep) { st = GLASS; ht = b.t; hid = b.id; camera_hit = false; }
-        PHASE(ctx.clk, 4);
-        // 6. the common case for everyone else
-        const bool go_on = shade_diffuse(path, s, M, hit, keep, a.n_bounces);
-        PHASE(ctx.clk, 5);
-        if (st == ACTIVE && !go_on) {
-            add_light(L, my_px, path.contrib, a.sample_cap);
-            st = FREE;
-        }
-        PHASE(ctx.clk, 6);
-    }
-    // p_color = totalLight / n_samples (main.cu:67); consecutive floats of consecutive pixels leave together
-    const RenderArgs le = lazy_args(a);
-    const float ns = (float)le.n_samples;
-    if (le.fb_layout == PT_FB_AOS) {
-        for (uint32_t f = lane; f < npx * 3u; f += 64u) {
-            const uint32_t px = (f * 43691u) >> 17;          // f / 3 for f < 2^16
-            le.fb[(size_t)L.out_px[px] * 3u + (f - px * 3u)] = ptw::from_fixed(L.acc[f]) / ns;
-        }
-    } else {
-        const size_t plane = le.fb_compact ? (size_t)le.n_lin : (size_t)le.max_x * (size_t)le.max_y;
-        if (lane < npx)
-            for (int c = 0; c < 3; c++) le.fb[c * plane + L.out_px[lane]] = ptw::from_fixed(L.acc[lane * 3 + c]) / ns;
-    }
-}
+    static PTD Surf surface(const Best& b, V3 o, V3 d, Ctx& c) { return ptf::surface(b, o, d, c.shade); }
+    static PTD Surf surface_parked(const Best& b, V3 pos, V3 d, Ctx& c) { return ptf::surface_at(b, pos, d, c.shade); }
+    static PTD V3 park_point(V3, V3 pos) { return pos; }
+    static PTD V3 camera_hit_point(V3 cam, V3 d, float t) { return madd(d, t, cam); }
+    static PTD void shade_emissive(Path& p, bool hit, const DMat& M) { ptf::shade_emissive(p, hit, M); }
+    static PTD bool shade_diffuse(Path& p, const Surf& s, const DMat& M, bool hit, bool keep, int n_bounces) { return ptf::shade_diffuse(p, s, M, hit, keep, n_bounces); }
+    static PTD bool shade_scatter(Path& p, const Surf& s, const DMat& M, float t, bool hit, int n_bounces, Ctx& c) { return ptf::shade_scatter(p, s, M, t, hit, n_bounces, c.clk); }
+    // albedo / max(albedo): what shade_diffuse leaves of a throughput of 1
+    static PTD V3 first_diffuse_coef(const DMat& M) { const V3 alb = ptf::v3(M.albedo[0], M.albedo[1], M.albedo[2]); return alb * rcp(max3(alb.x, alb.y, alb.z)); }
+    static PTD void idle(Path& p) { T::idle(p); }
+    static PTD void phase(Ctx& c, int i) { PHASE(c.clk, i); (void)c; (void)i; }
+};
 
 template <bool LDS_TABLES, bool SORTED, int KM>
 __global__ __launch_bounds__(ptw::BLOCK) void render_fast_batched_kernel(RenderArgs a, uint32_t n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     const uint32_t P = 1u << a.tile_log2;
-    const size_t per_wave = batched_wave_bytes(P, (uint32_t)a.q_cap);
+    const size_t per_wave = ptb::batched_wave_bytes(P, (uint32_t)a.q_cap);
     FastCtx ctx;
     if (LDS_TABLES) {
         // The whole workgroup copies the shading and material tables into LDS once.
@@ -1453,12 +1136,12 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_batched_kernel(RenderA
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t tile = blockIdx.x * ptw::WAVES_PER_BLOCK + wave;
     if (tile >= n_tiles) return;
-    const uint32_t wave_lds = lds_off(dyn_lds + per_wave * wave);
-    BatchLds L;
-    carve_wave_lds(wave_lds, P, (uint32_t)a.q_cap, L, ctx);
+    ptb::BatchLds L;
+    ptb::carve_wave_lds(ptb::lds_off(dyn_lds + per_wave * wave), P, (uint32_t)a.q_cap, L);
+    ctx.pxt = L.pxt; ctx.pxs = P;
     ctx.wstack = nullptr;
     ctx.clk.start();
-    render_tile_batched<LDS_TABLES, SORTED, KM>(a, tile, L, ctx);
+    ptb::render_tile_batched<FastBatched<SORTED, KM>>(a, tile, L, ctx);
     ctx.clk.flush(threadIdx.x & 63);
 }
 
@@ -1644,7 +1327,7 @@ int ptk_render_fast(const RenderArgs& a, int variant, hipStream_t s) {
             // The loop with camera batches and the glass queue.  All of its LDS is dynamic: per-wave arrays sized by the tile, the
             // queue by q_cap, the tables by the scene.
             const size_t table_bytes = tables ? (size_t)a.n_prims * sizeof(FShade) + (size_t)a.n_mats * sizeof(DMat) : 0;
-            const size_t lds = batched_wave_bytes(1u << a.tile_log2, (uint32_t)a.q_cap) * ptw::WAVES_PER_BLOCK + table_bytes;
+            const size_t lds = ptb::batched_wave_bytes(1u << a.tile_log2, (uint32_t)a.q_cap) * ptw::WAVES_PER_BLOCK + table_bytes;
 #define PT_LAUNCH_BATCHED(T, KM) hipLaunchKernelGGL((render_fast_batched_kernel<T, true, KM>), dim3(blocks), dim3(ptw::BLOCK), lds, s, a, n_tiles)
             if (tables) { if (short_only) PT_LAUNCH_BATCHED(true, KM_SHORT); else if (general_only) PT_LAUNCH_BATCHED(true, KM_GENERAL); else PT_LAUNCH_BATCHED(true, KM_ALL); }
             else { if (short_only) PT_LAUNCH_BATCHED(false, KM_SHORT); else if (general_only) PT_LAUNCH_BATCHED(false, KM_GENERAL); else PT_LAUNCH_BATCHED(false, KM_ALL); }

@@ -2,6 +2,7 @@
 // -ffp-contract=off (see Makefile): every float operation rounds on its own.
 #include "pt_parity.h"
 #include "pt_wavepool.h"
+#include "pt_batched.h"
 
 using namespace ptp;
 
@@ -52,6 +53,98 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_parity_kernel(RenderArgs a,
     if (tile >= n_tiles) return;
     ParityCtx ctx;
     ptw::render_tile<ParityTracer>(a, tile, lds[wave].refs(), stash[wave], ctx);
+}
+
+// The reference's operation order for the loop of pt_batched.h (scenes without a hierarchy, bsdf.h shading): typed
+// loops over the table sorted by shape type, camera batches that test only their tile's candidates, and the common
+// diffuse case shaded in the loop body while hits that need Beer term, Fresnel ratio and the other directions are set
+// aside and shaded together.  Every float operation of a path is the plain loop's (path_step), so the image is
+// render_parity_kernel's bit for bit.  A set-aside hit keeps its ray's origin: the winner's record is rebuilt from the
+// ray in local space, as the reference does (shapes.h:42-48,125-129).
+struct ParityBatched {
+    using V3 = ptp::V3;
+    using Path = ptp::Path;
+    struct Best { float t; int id; };                  // id = (primitive << 3) | surface code, negative = miss
+    struct Surf { V3 pos, nrm; bool inside; int material; };
+    struct Ctx { const DMat* mats; const DPrim* prims; float* pxt; uint32_t pxs; };
+    using Scene = PScene;
+    static __device__ __forceinline__ V3 v3(float x, float y, float z) { return ptp::v3(x, y, z); }
+    static __device__ __forceinline__ Scene scene(const RenderArgs& a) { return a.pscene; }
+    // Lane px prepares pixel px of the tile: i - 0.5 and max_y - j - 0.5 of main.cu:62 (both exact in float) and the
+    // pixel's RNG key.
+    static __device__ __forceinline__ void prologue(const RenderArgs& a, Ctx& c, uint32_t px, const ptw::PixelRef& ref) {
+        c.pxt[px] = ref.i - 0.5f;
+        c.pxt[c.pxs + px] = a.max_y - ref.j - 0.5f;
+        c.pxt[2u * c.pxs + px] = __uint_as_float(rng_hash(ref.index ^ a.seed_hash));
+    }
+    static __device__ __forceinline__ void make_ray(const RenderArgs& a, Ctx& c, uint32_t px, uint32_t sample, float4& ray) {
+        const uint32_t key = rng_hash(__float_as_uint(c.pxt[2u * c.pxs + px]) + 0x9E3779B9u * (sample + 1u));
+        V3 o, d;
+        camera_ray_at(a, c.pxt[px], c.pxt[c.pxs + px], key, &o, &d);
+        ray = make_float4(d.x, d.y, d.z, __uint_as_float(key));
+    }
+    static __device__ __forceinline__ const float* cull_boxes(const RenderArgs& a, int& n) { n = a.pscene.n_prims; return a.pscene.boxes; }
+    static __device__ __forceinline__ Best pack(const Nearest& n) { Best b; b.t = n.t; b.id = n.prim < 0 ? -8 : ((n.prim << 3) | n.surf); return b; }
+    static __device__ __forceinline__ Best scan(V3 o, V3 d, const Scene& S) { return pack(nearest_scan_typed<false>(o, d, S, ~0ull)); }
+    static __device__ __forceinline__ Best scan_camera(V3 o, V3 d, const Scene& S, const RenderArgs&, unsigned long long cand) {
+        if (S.boxes != nullptr && S.n_prims <= 64) return pack(nearest_scan_typed<true>(o, d, S, cand));
+        return pack(nearest_scan_typed<false>(o, d, S, ~0ull));
+    }
+    static __device__ __forceinline__ Surf surface(const Best& b, V3 o, V3 d, Ctx& c) {
+        Nearest n; n.prim = b.id >> 3; n.t = b.t; n.surf = b.id & 7;
+        const Hit h = finish_hit(n, o, d, c.prims);
+        Surf s; s.pos = h.pos; s.nrm = h.nrm; s.inside = h.inside; s.material = c.prims[n.prim].material;
+        return s;
+    }
+    static __device__ __forceinline__ Surf surface_parked(const Best& b, V3 o, V3 d, Ctx& c) { return surface(b, o, d, c); }
+    static __device__ __forceinline__ V3 park_point(V3 o, V3) { return o; }
+    static __device__ __forceinline__ V3 camera_hit_point(V3 cam, V3, float) { return cam; }
+    static __device__ __forceinline__ Hit as_hit(const Surf& s, float t) { Hit h; h.prim = 0; h.t = t; h.pos = s.pos; h.nrm = s.nrm; h.inside = s.inside; return h; }
+    static __device__ __forceinline__ void shade_emissive(Path& p, bool hit, const DMat& M) { step_emissive(p, hit, M); }
+    static __device__ __forceinline__ bool shade_diffuse(Path& p, const Surf& s, const DMat& M, bool hit, bool keep, int n_bounces) {
+        return step_diffuse(p, as_hit(s, 0.0f), hit, keep, M, n_bounces);
+    }
+    static __device__ __forceinline__ bool shade_scatter(Path& p, const Surf& s, const DMat& M, float t, bool hit, int n_bounces, Ctx&) {
+        return step_scatter(p, as_hit(s, t), hit, M, n_bounces);
+    }
+    // what step_diffuse leaves of a throughput of 1: (1 * albedo) / max(albedo)
+    static __device__ __forceinline__ V3 first_diffuse_coef(const DMat& M) {
+        const V3 coef = ptp::v3(1.0f, 1.0f, 1.0f) * ptp::v3(M.albedo[0], M.albedo[1], M.albedo[2]);
+        return coef / fmaxf(coef.x, fmaxf(coef.y, coef.z));
+    }
+    // a lane without a path steps a harmless ray that is not degenerate (a zero direction would send the wave's
+    // search down the scene-order loop)
+    static __device__ __forceinline__ void idle(Path& p) {
+        p.o = ptp::v3(0.0f, 0.0f, 0.0f); p.d = ptp::v3(0.0f, 0.0f, 1.0f);
+        p.coef = ptp::v3(0.0f, 0.0f, 0.0f); p.contrib = ptp::v3(0.0f, 0.0f, 0.0f); p.key = 0; p.seg = 0;
+    }
+    static __device__ __forceinline__ void phase(Ctx&, int) {}
+};
+
+template <bool LDS_MATS>
+__global__ __launch_bounds__(ptw::BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void render_parity_batched_kernel(RenderArgs a, uint32_t n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    const uint32_t P = 1u << a.tile_log2;
+    const size_t per_wave = ptb::batched_wave_bytes(P, (uint32_t)a.q_cap);
+    ParityBatched::Ctx ctx;
+    ctx.prims = a.pscene.prims;
+    if (LDS_MATS) {
+        DMat* lmats = reinterpret_cast<DMat*>(dyn_lds + per_wave * ptw::WAVES_PER_BLOCK);
+        const uint32_t* gm = reinterpret_cast<const uint32_t*>(a.mats);
+        uint32_t* lm = reinterpret_cast<uint32_t*>(lmats);
+        for (uint32_t w = threadIdx.x; w < (uint32_t)a.n_mats * (sizeof(DMat) / 4); w += ptw::BLOCK) lm[w] = gm[w];
+        __syncthreads();
+        ctx.mats = lmats;
+    } else {
+        ctx.mats = a.mats;
+    }
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * ptw::WAVES_PER_BLOCK + wave;
+    if (tile >= n_tiles) return;
+    ptb::BatchLds L;
+    ptb::carve_wave_lds(ptb::lds_off(dyn_lds + per_wave * wave), P, (uint32_t)a.q_cap, L);
+    ctx.pxt = L.pxt; ctx.pxs = P;
+    ptb::render_tile_batched<ParityBatched>(a, tile, L, ctx);
 }
 
 __device__ __forceinline__ V3 load3(const float* p, int i) { return v3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
@@ -138,7 +231,15 @@ int ptk_render_parity(const RenderArgs& a, hipStream_t s) {
     if (a.n_lin == 0) return 0;
     const uint32_t n_tiles = (a.n_lin + (1u << a.tile_log2) - 1u) >> a.tile_log2;
     const uint32_t blocks = (n_tiles + ptw::WAVES_PER_BLOCK - 1) / ptw::WAVES_PER_BLOCK;
-    hipLaunchKernelGGL(render_parity_kernel, dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+    if (a.q_cap > 0) {
+        // the loop with camera batches (pt_render sets q_cap for scenes it can serve)
+        const bool lds_mats = a.n_mats <= 32;
+        const size_t lds = ptb::batched_wave_bytes(1u << a.tile_log2, (uint32_t)a.q_cap) * ptw::WAVES_PER_BLOCK + (lds_mats ? (size_t)a.n_mats * sizeof(DMat) : 0u);
+        if (lds_mats) hipLaunchKernelGGL(render_parity_batched_kernel<true>, dim3(blocks), dim3(ptw::BLOCK), lds, s, a, n_tiles);
+        else hipLaunchKernelGGL(render_parity_batched_kernel<false>, dim3(blocks), dim3(ptw::BLOCK), lds, s, a, n_tiles);
+    } else {
+        hipLaunchKernelGGL(render_parity_kernel, dim3(blocks), dim3(ptw::BLOCK), 0, s, a, n_tiles);
+    }
     PT_CHECK(hipGetLastError());
     return 0;
 }

@@ -28,12 +28,12 @@ PTD V3 normalized(V3 a) {
     if (n > 0.0f) { float s = sqrtf(n); return v3(a.x / s, a.y / s, a.z / s); }
     return a;
 }
-// Affine3f * point and linear() * vector for a row-major [L | t] block.
-PTD V3 xvec(const float* m, V3 p) {
+// Affine3f * point and linear() * vector for a row-major [L | t] block.  (MP: a pointer to floats in any address space.)
+template <class MP> PTD V3 xvec(MP m, V3 p) {
     return v3(m[0] * p.x + (m[1] * p.y + m[2] * p.z), m[4] * p.x + (m[5] * p.y + m[6] * p.z),
               m[8] * p.x + (m[9] * p.y + m[10] * p.z));
 }
-PTD V3 xpoint(const float* m, V3 p) {
+template <class MP> PTD V3 xpoint(MP m, V3 p) {
     V3 l = xvec(m, p);
     return v3(l.x + m[3], l.y + m[7], l.z + m[11]);
 }
@@ -79,7 +79,7 @@ struct LHit {
 PTD LHit lhit_none() { LHit h; h.n = 0; h.h1 = false; h.h2 = false; h.t1 = 0.0f; h.t2 = 0.0f; h.s1 = 0; h.s2 = 0; return h; }
 
 // Plane::getRayPath (shapes.h:116-133); out of bounds or parallel => 0 hits.
-PTD LHit plane_local(V3 o, V3 d, const float* b) {
+template <class MP> PTD LHit plane_local(V3 o, V3 d, MP b) {
     LHit h = lhit_none();
     float dz = d.x * 0.0f + (d.y * 0.0f + d.z * 1.0f);
     if (dz != 0.0f) {
@@ -260,6 +260,113 @@ PTD void nearest_consider(Nearest& best, V3 o, V3 d, const DPrim& P, int k) {
     if (valid && (best.prim < 0 || t < best.t || (TIES && t == best.t && k < best.prim))) { best.prim = k; best.t = t; best.surf = surf; }
 }
 
+// Records that every lane reads at the same, wave-uniform address are read through a pointer to the constant address
+// space: such loads are scalar loads (one fetch per wave, operands in scalar registers) whatever else the kernel
+// writes to memory.
+typedef const DPrim __attribute__((address_space(4)))* KPrimP;
+
+// One record of known shape type for the typed loops: the local test (Plane / Cube / Sphere::getRayPath), the filter
+// of Shape::getIntersections (shapes.h:62-73) and the choice between first and second of getNearestIntersection
+// (shapes.h:86-92) written without branches — every lane computes every value and the conditions are combined at
+// the end, so a record's fields are fetched together and no lane waits for another's branch.  The float operations
+// and their order are plane_local's, cube_local's and sphere_local's; values a branch of those would not have
+// computed (a quotient by zero, the root of a negative number) are computed here and discarded.
+//   two distances t1, t2 that both exist: both <= EPS -> none; only t1 <= EPS -> t2; only t2 <= EPS -> t1;
+//   otherwise t2 if t2 < t1, else t1.
+PTD float nearer_of_two(float t1, float t2, bool& none) {
+    const float EPS = 1e-5f;
+    const bool a = t1 <= EPS, b = t2 <= EPS;
+    none = a & b;
+    return a ? t2 : (b ? t1 : (t2 < t1 ? t2 : t1));
+}
+template <int TYPE>
+PTD void nearest_consider_typed(Nearest& best, V3 o, V3 d, KPrimP P, int k) {
+    V3 ol = xpoint(P->inv, o);
+    V3 dl = xvec(P->inv, d);
+    bool valid; float t; int surf = 0;
+    if (TYPE == PT_PLANE) {                                                     // shapes.h:116-133
+        float dz = dl.x * 0.0f + (dl.y * 0.0f + dl.z * 1.0f);
+        V3 no = -1.0f * ol;
+        t = (no.x * 0.0f + (no.y * 0.0f + no.z * 1.0f)) / dz;
+        V3 pos = ol + dl * t;
+        valid = (dz != 0.0f) & (P->bounds[0] < pos.x) & (P->bounds[1] < pos.y) & (P->bounds[2] > pos.x) & (P->bounds[3] > pos.y) & !(t <= 1e-5f);
+    } else if (TYPE == PT_CUBE) {                                               // shapes.h:171-220
+        float x = 1.0f / dl.x, y = 1.0f / dl.y, z = 1.0f / dl.z;
+        float t1 = (-0.5f - ol.x) * x, t2 = (0.5f - ol.x) * x;
+        float t3 = (-0.5f - ol.y) * y, t4 = (0.5f - ol.y) * y;
+        float t5 = (-0.5f - ol.z) * z, t6 = (0.5f - ol.z) * z;
+        float tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+        float tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+        bool none;
+        t = nearer_of_two(tmin, tmax, none);
+        valid = !(tmax < 0.0f) & !(tmin > tmax) & !none;
+    } else if (TYPE == PT_SPHERE) {                                             // shapes.h:327-360
+        float a = dot(dl, dl);
+        float b = 2.0f * dot(dl, ol);
+        float c = dot(ol, ol) - 0.25f;
+        float disc = b * b - 4 * a * c;
+        // (most waves miss a small sphere with every lane: the root and the two quotients are then skipped)
+        if (__ballot(!(disc < 0.0f)) == 0ull) return;
+        float sq = sqrtf(disc);
+        float den = 2.0f * a;
+        bool none;
+        t = nearer_of_two((-b - sq) / den, (-b + sq) / den, none);
+        valid = !(disc < 0.0f) & !none;
+    } else {
+        LHit h = cyl_local(ol, dl);
+        eps_filter(h);
+        if (h.n == 1) { valid = h.h1; t = h.t1; surf = h.s1; }
+        else if (h.n == 2) {
+            bool second = h.t2 < h.t1;
+            valid = second ? h.h2 : h.h1; t = second ? h.t2 : h.t1; surf = second ? h.s2 : h.s1;
+        } else { valid = false; t = 0.0f; surf = 0; }
+    }
+    const bool take = valid & ((best.prim < 0) | (t < best.t) | ((t == best.t) & (k < best.prim)));
+    best.prim = take ? k : best.prim;
+    best.t = take ? t : best.t;
+    best.surf = take ? surf : best.surf;
+}
+
+// A ray whose distances can come out as NaN: a zero direction (refract's zero vector on total reflection,
+// vec_math.h:27, survives .normalized()) or a component that is not finite.  With a NaN in play the strict '<' of
+// shapes.h:93 depends on the order of the tests, so such rays are searched in scene order.
+PTD bool degenerate_ray(V3 o, V3 d) {
+    const float dd = sqn(d), oo = sqn(o);
+    return !(dd > 0.0f && dd < __builtin_inff() && oo < __builtin_inff());
+}
+
+// getNearestIntersection over the table sorted by shape type: one typed loop per type, records [first, last) of each;
+// `mask` (bit s = record s of the sorted table) leaves out records no ray of the caller can hit.  For rays whose
+// distances are numbers the (distance, scene index) rule gives the loop's result in any order of the tests; a wave
+// that holds a degenerate ray takes the loop in scene order.
+template <bool MASKED>
+PTD Nearest nearest_scan_typed(V3 o, V3 d, const PScene& S, unsigned long long mask) {
+    Nearest best; best.prim = -1; best.t = 0.0f; best.surf = 0;
+    if (__ballot(degenerate_ray(o, d)) != 0ull) {
+        for (int k = 0; k < S.n_prims; k++) nearest_consider<false>(best, o, d, S.prims[k], k);
+        return best;
+    }
+#define PT_TYPE_LOOP(TYPE)                                                                                  \
+    if (MASKED) {                                                                                            \
+        const int first = S.type_first[TYPE], cnt = S.type_first[TYPE + 1] - first;                         \
+        unsigned long long m = cnt > 0 ? (mask >> first) & (cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull)) : 0ull; \
+        for (; m != 0ull; m &= m - 1ull) {                                                                   \
+            const KPrimP P = (KPrimP)S.by_type + (first + __builtin_ctzll(m));                               \
+            nearest_consider_typed<TYPE>(best, o, d, P, P->index);                                           \
+        }                                                                                                    \
+    } else {                                                                                                 \
+        KPrimP P = (KPrimP)S.by_type + S.type_first[TYPE];                                                   \
+        for (int n = S.type_first[TYPE + 1] - S.type_first[TYPE]; n > 0; n--, P++)                           \
+            nearest_consider_typed<TYPE>(best, o, d, P, P->index);                                           \
+    }
+    PT_TYPE_LOOP(PT_PLANE)
+    PT_TYPE_LOOP(PT_CUBE)
+    PT_TYPE_LOOP(PT_CYLINDER)
+    PT_TYPE_LOOP(PT_SPHERE)
+#undef PT_TYPE_LOOP
+    return best;
+}
+
 // The loop of getNearestIntersection (shapes.h:79-100): k is wave-uniform, so
 // prims[k] is fetched with scalar loads and the type switch is a scalar branch.
 // A scene with a bounding-volume hierarchy (S.nodes) is searched through it instead: the primitives outside it in
@@ -305,10 +412,8 @@ struct Hit {
     bool inside;
 };
 
-// getNearestIntersection including the winner's record (shapes.h:93-97).
-PTD Hit nearest_hit(V3 o, V3 d, const PScene& S) {
-    const DPrim* prims = S.prims;
-    Nearest b = nearest_scan(o, d, S);
+// The winner's record (shapes.h:93-97) from the search's result.
+PTD Hit finish_hit(const Nearest& b, V3 o, V3 d, const DPrim* prims) {
     Hit h; h.prim = b.prim; h.t = b.t; h.pos = v3(0, 0, 0); h.nrm = v3(0, 0, 0); h.inside = false;
     if (b.prim >= 0) {
         const DPrim& P = prims[b.prim];
@@ -320,6 +425,8 @@ PTD Hit nearest_hit(V3 o, V3 d, const PScene& S) {
     }
     return h;
 }
+// getNearestIntersection including the winner's record.
+PTD Hit nearest_hit(V3 o, V3 d, const PScene& S) { return finish_hit(nearest_scan(o, d, S), o, d, S.prims); }
 
 // ---- bsdf.h ---------------------------------------------------------------------
 PTD V3 reflect(V3 v, V3 n) { return v - 2 * (dot(v, n) * n); }                  // vec_math.h:19-21
@@ -374,13 +481,13 @@ struct Path {
 // One exit and unconditional updates of o, d, coef: a lane whose path ends here is refilled before that state is read
 // again, so it may hold anything, and the old and new state never have to coexist in registers.  A miss goes through
 // the arithmetic with primitive 0's material and is dropped at the end; the arithmetic of a live path is untouched.
-PTD bool path_step(Path& p, const PScene& S, const DMat* __restrict__ mats, int n_bounces) {
-    const DPrim* prims = S.prims;
-    Hit h = nearest_hit(p.o, p.d, S);
-    const bool hit = h.prim >= 0;
-    const DMat& M = mats[prims[hit ? h.prim : 0].material];
+PTD void step_emissive(Path& p, bool hit, const DMat& M) {                      // bsdf.h:90-92
     V3 emissive = v3(M.emissive[0], M.emissive[1], M.emissive[2]);
     if (hit && sqn(emissive) > 0.0f) p.contrib = p.contrib + emissive * p.coef;
+}
+
+// bsdf.h:95-165 for the hit `h` (h.prim: whether there is one) on material M; true = the path goes on.
+PTD bool step_scatter(Path& p, const Hit& h, bool hit, const DMat& M, int n_bounces) {
     if (p.seg > 0 && h.inside) {
         V3 rc = v3(M.refractionColor[0], M.refractionColor[1], M.refractionColor[2]);
         V3 att = (-1.0f * rc) * h.t;
@@ -433,6 +540,33 @@ PTD bool path_step(Path& p, const PScene& S, const DMat* __restrict__ mats, int 
     p.d = ndir;
     p.seg++;
     return !dead && p.seg <= n_bounces;
+}
+
+// What step_scatter computes for a material with f0 = 0 and transparency = 0 hit from outside (or on the first
+// segment): no Beer term, p_specular = p_refract = 0, no mode draw, mode 3, p_ray = max(1 - (0 + 0), 0.001) = 1 and
+// coef / 1 = coef, (coef * 1) / q = coef / q exactly.  The operations that remain are step_scatter's, in its order, so
+// the path comes out bit for bit the same.  `keep` lanes (hits that need step_scatter) come out unchanged.
+PTD bool step_diffuse(Path& p, const Hit& h, bool hit, bool keep, const DMat& M, int n_bounces) {
+    const uint32_t slot = 2u + 6u * (uint32_t)p.seg;
+    const V3 dd = normalized(h.nrm + sample_hemisphere(rng_u_first(p.key, slot + 1u), rng_u_second(p.key, slot + 1u)));
+    V3 coef = p.coef * v3(M.albedo[0], M.albedo[1], M.albedo[2]);
+    const float q = fmaxf(coef.x, fmaxf(coef.y, coef.z));
+    const bool dead = !hit || rng_u(p.key, slot + 5u) > q;
+    coef = coef / q;
+    p.coef = v3(keep ? p.coef.x : coef.x, keep ? p.coef.y : coef.y, keep ? p.coef.z : coef.z);
+    p.d = v3(keep ? p.d.x : dd.x, keep ? p.d.y : dd.y, keep ? p.d.z : dd.z);
+    p.o = v3(keep ? p.o.x : h.pos.x, keep ? p.o.y : h.pos.y, keep ? p.o.z : h.pos.z);
+    p.seg += keep ? 0 : 1;
+    return !dead && p.seg <= n_bounces;
+}
+
+PTD bool path_step(Path& p, const PScene& S, const DMat* __restrict__ mats, int n_bounces) {
+    const DPrim* prims = S.prims;
+    Hit h = nearest_hit(p.o, p.d, S);
+    const bool hit = h.prim >= 0;
+    const DMat& M = mats[prims[hit ? h.prim : 0].material];
+    step_emissive(p, hit, M);
+    return step_scatter(p, h, hit, M, n_bounces);
 }
 
 // ---- bsdf_alternative.h: the class-based BSDFs and their tracePath -------------------------
@@ -507,14 +641,16 @@ PTD bool path_step_alt(Path& p, const PScene& S, const DMat* __restrict__ mats, 
     return p.seg <= n_bounces;
 }
 
-// Camera ray of (pixel i,j; sample) exactly as render builds it (main.cu:62-64).
-PTD void camera_ray(const RenderArgs& a, int i, int j, uint32_t key, V3* o, V3* d) {
+// Camera ray of (pixel i,j; sample) exactly as render builds it (main.cu:62-64); ci = i - 0.5f and
+// cj = max_y - j - 0.5f are the caller's (both exact in float).
+PTD void camera_ray_at(const RenderArgs& a, float ci, float cj, uint32_t key, V3* o, V3* d) {
     float jx = rng_u_first(key, 0u), jy = rng_u_second(key, 0u);
-    float sx = (i - 0.5f + jx), sy = (a.max_y - j - 0.5f + jy);
+    float sx = (ci + jx), sy = (cj + jy);
     V3 pc = v3((a.p00[0] + a.du * sx) + 0.0f * sy, (a.p00[1] + 0.0f * sx) + a.dv * sy, (a.p00[2] + 0.0f * sx) + 0.0f * sy);
     V3 cam = v3(a.cam[0], a.cam[1], a.cam[2]);
     *o = cam;
     *d = normalized(pc - cam);
 }
+PTD void camera_ray(const RenderArgs& a, int i, int j, uint32_t key, V3* o, V3* d) { camera_ray_at(a, i - 0.5f, a.max_y - j - 0.5f, key, o, d); }
 
 }  // namespace ptp

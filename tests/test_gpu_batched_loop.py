@@ -103,6 +103,45 @@ def test_batched_loop_equals_plain_loop_bitwise(torch, pt):
         assert float(ref.sum()) > 0.0, name
 
 
+def test_parity_order_batched_loop_equals_its_plain_loop_bitwise(torch, pt):
+    """PT_MATH_PARITY on a scene without a hierarchy runs the same loop (typed loops over the table sorted by shape
+    type, camera batches over the tile's candidates, diffuse hits shaded in the loop body, the others set aside) with
+    the reference's operation order: every float operation of a path is the plain parity-order loop's, so the two
+    images are equal bit for bit.  The plain loop is what PT_TUNE_GLASS_QUEUE = -1 runs."""
+    from pathtracer_amd import binding as b
+    for name, (scene_data, depth) in _scenes(pt).items():
+        scene = pt.Scene(*scene_data)
+        for (w, h, spp, extra) in CONFIGS + [(150, 80, 6, dict(n_bounces=0)), (150, 80, 6, dict(n_bounces=1))]:
+            kw = dict(extra)
+            kw.setdefault("n_bounces", depth)
+            cfg = pt.make_config(w, h, spp, math_mode=pt.PT_MATH_PARITY, **kw)
+            rows = pt.rendered_rows(cfg) if kw.get("fb_compact") else h
+            shape = (rows, w, 3) if kw.get("fb_layout", 0) == 0 else (3, rows, w)
+            fresh = lambda: torch.full(shape, -5.0, dtype=torch.float32, device="cuda")
+            scene.tune(b.PT_TUNE_GLASS_QUEUE, -1)
+            ref = scene.render(cfg, out=fresh())
+            for cap, gate in ((0, 0), (8, 1), (64, 64)):
+                scene.tune(b.PT_TUNE_GLASS_QUEUE, cap).tune(b.PT_TUNE_GLASS_GATE, gate)
+                img = scene.render(cfg, out=fresh())
+                assert torch.equal(img, ref), (name, (w, h, spp, extra), cap, gate)
+            scene.tune(b.PT_TUNE_GLASS_QUEUE, 0).tune(b.PT_TUNE_GLASS_GATE, 0)
+        assert float(ref[ref != -5.0].sum()) > 0.0, name
+
+
+def test_parity_order_loops_agree_on_the_headline_frame(torch, pt):
+    """The 1920x1080 @ 64 spp frame of the default scene and a 960x540 @ 16 frame of the glass grid at depth 31,
+    PT_MATH_PARITY: the loop with camera batches and the plain loop, bit for bit."""
+    from pathtracer_amd import binding as b
+    for data, w, h, spp, depth in ((pt.default_scene(), 1920, 1080, 64, 5), (pt.glass_grid_scene(5), 960, 540, 16, 31)):
+        scene = pt.Scene(*data)
+        cfg = pt.make_config(w, h, spp, n_bounces=depth, math_mode=pt.PT_MATH_PARITY)
+        scene.tune(b.PT_TUNE_GLASS_QUEUE, -1)
+        plain = scene.render(cfg)
+        scene.tune(b.PT_TUNE_GLASS_QUEUE, 0)
+        batched = scene.render(cfg)
+        assert torch.equal(plain, batched), (w, h, spp, depth)
+
+
 def test_camera_elsewhere_and_looking_at_nothing(torch, pt):
     """Another camera position (the culling test works relative to it), and a view in which most tiles see no
     primitive at all: batches that park nothing must not stall the wave."""

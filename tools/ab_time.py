@@ -1,6 +1,6 @@
 """A/B timing of two builds of the library on the 1080p frame, interleaved rounds in one process (development aid).
     python tools/ab_time.py pathtracer_amd/libpt_hip.so pathtracer_amd/libpt_hip_exp.so
-AB_SCENE=synthetic|glassN (default: the default scene), AB_SPP, AB_DEPTH choose another frame; a library given as
+AB_SCENE=synthetic|glassN (default: the default scene), AB_SPP, AB_DEPTH, AB_MODE (math_mode) choose another frame; a library given as
 path@knob=value[,knob=value] gets pt_scene_tune(knob, value) on its scene (knob numbers of include/pt_hip.h)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,7 +22,8 @@ for arg in sys.argv[1:]:
         k, v = kv.split("=")
         assert L.pt_scene_tune(h, int(k), int(v)) == 0, kv
     libs.append((arg, L, h))
-cfg = b.make_config(1920, 1080, int(os.environ.get("AB_SPP", "64")), n_bounces=int(os.environ.get("AB_DEPTH", "5")))
+cfg = b.make_config(1920, 1080, int(os.environ.get("AB_SPP", "64")), n_bounces=int(os.environ.get("AB_DEPTH", "5")),
+                    math_mode=int(os.environ.get("AB_MODE", str(b.PT_MATH_FAST))))
 fb = torch.zeros((1080, 1920, 3), device="cuda")
 times = {p: [] for p, _, _ in libs}
 sums = {}
