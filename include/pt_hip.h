@@ -177,8 +177,22 @@ float pt_focal_length(int nx, int ny, float v_height, float fov_deg);
  * (an infinite radiance included), so a sum never leaves the range; a NaN sample
  * adds nothing where the reference would turn the pixel NaN.  A scene whose own
  * lights exceed that cap (n_samples x largest emissive component > 2^30) is
- * refused.  n_samples is at most 2^24. */
+ * refused.  n_samples is at most 2^24, n_bounces below 2^24. */
 int pt_render(const pt_scene* scene, const pt_config* cfg, float* d_fb, void* stream);
+
+/* The sample loop of main.cu:61-67 in pieces.  pt_render_samples traces samples [sample_begin, sample_begin +
+ * sample_count) of the cfg->n_samples that make up the frame (sample s of a pixel draws from the same random stream
+ * whichever call traces it) and ADDS each pixel's sum of radiance, as signed 32.32 fixed point, to d_sums: 64-bit
+ * integers laid out like the framebuffer (pt_sums_count(cfg) of them: rows x max_x x 3, the rows being all of the image
+ * or, with fb_compact, the rendered ones), zeroed by the caller before the first piece (hipMemsetAsync).  The additions
+ * are atomic, so pieces may run on different streams.  pt_resolve writes d_fb = sum / n_samples for the rendered rows.
+ * Integer sums do not depend on how the samples were cut up: the frame is pt_render's bit for bit.  What a long render
+ * needs to be resumed is d_sums and the number of samples done.  The reference has no counterpart (its loop runs inside
+ * one launch). */
+int pt_render_samples(const pt_scene* scene, const pt_config* cfg, int sample_begin, int sample_count,
+                      unsigned long long* d_sums, void* stream);
+long long pt_sums_count(const pt_config* cfg);   /* -1: bad size or rows */
+int pt_resolve(const pt_scene* scene, const pt_config* cfg, const unsigned long long* d_sums, float* d_fb, void* stream);
 
 /* Shape::getIntersections (filter != 0; shapes.h:60-75) or Shape::getRayPath
  * (filter == 0, rays taken as already local; shapes.h:58) of primitive `prim`

@@ -162,7 +162,7 @@ PTB uint32_t camera_batch(const RenderArgs& a, typename X::Ctx& ctx, const Batch
     const uint32_t px = w & (P - 1u);
     const bool valid = w < total && px < npx;
     float4 ray;
-    X::make_ray(a, ctx, px, w >> lg, ray);
+    X::make_ray(a, ctx, px, (w >> lg) + (uint32_t)a.sample_begin, ray);
     const V3 o = X::v3(a.cam[0], a.cam[1], a.cam[2]), d = X::v3(ray.x, ray.y, ray.z);
     const uint32_t key = __float_as_uint(ray.w);
     const Best b0 = X::scan_camera(o, d, sc, a, cand);
@@ -371,6 +371,11 @@ PTB void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds&
     }
     // p_color = totalLight / n_samples (main.cu:67); consecutive floats of consecutive pixels leave together
     const RenderArgs le = lazy_args(a);
+    if (le.sums != nullptr) {
+        ptw::WaveLds l; l.acc = L.acc; l.out_px = L.out_px;
+        ptw::store_tile(le, l, npx, lane);
+        return;
+    }
     const float ns = (float)le.n_samples;
     if (le.fb_layout == PT_FB_AOS) {
         for (uint32_t f = lane; f < npx * 3u; f += 64u) {

@@ -816,10 +816,18 @@ int pt_scene_tune(pt_scene* sc, int knob, int value) {
 int pt_scene_device(const pt_scene* sc) { return sc ? sc->device : -1; }
 int pt_scene_bvh_nodes(const pt_scene* sc) { return sc ? sc->n_bnodes : -1; }
 
-int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* stream) {
-    if (!sc || !cfg || !d_fb) return PT_FAIL("pt_render: null argument");
+}  // extern "C"
+
+// pt_render (sums == null: all of cfg->n_samples, floats to d_fb) and pt_render_samples (samples [sample_begin,
+// sample_begin + sample_count) of them, 32.32 sums added to `sums`).
+static int render_launch(const pt_scene* sc, const pt_config* cfg, float* d_fb, int sample_begin, int sample_count,
+                         unsigned long long* sums, void* stream) {
+    if (!sc || !cfg || (!d_fb && !sums)) return PT_FAIL("pt_render: null argument");
     if (cfg->max_x <= 0 || cfg->max_y <= 0 || cfg->n_samples <= 0 || cfg->n_bounces < 0)
         return PT_FAIL("pt_render: bad image size, n_samples or n_bounces");
+    if (cfg->n_bounces >= (1 << 24)) return PT_FAIL("pt_render: n_bounces above 2^24");   // (a set-aside hit packs the segment number into 24 bits)
+    if (sample_begin < 0 || sample_count <= 0 || (long long)sample_begin + sample_count > cfg->n_samples)
+        return PT_FAIL("pt_render_samples: the sample range must lie inside [0, n_samples)");
     if (cfg->n_samples > (1 << 24)) return PT_FAIL("pt_render: n_samples above 2^24");
     // Pixel sums are 32.32 fixed point and a sample counts up to 2^30 / n_samples (ptw::to_fixed), so a sum cannot
     // leave the range; a light whose own emission is beyond that cap would be dimmed silently, so it is refused.
@@ -851,7 +859,8 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     }
     a.du = du[0]; a.dv = dv[1];
     a.max_x = cfg->max_x; a.max_y = cfg->max_y;
-    a.n_samples = cfg->n_samples; a.n_bounces = cfg->n_bounces; a.bsdf_model = cfg->bsdf_model;
+    a.n_samples = sample_count; a.sample_begin = sample_begin; a.sums = sums;
+    a.n_bounces = cfg->n_bounces; a.bsdf_model = cfg->bsdf_model;
     a.sample_cap = 1073741824.0f / (float)cfg->n_samples;
     a.seed_hash = host_hash(cfg->seed + 0x9E3779B9u);
     const int row_step = cfg->row_step == 0 ? 1 : cfg->row_step;
@@ -875,7 +884,7 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     // ... and a pool of at least ~2048 samples per wave, or the drain phase dominates at low sample counts (10 000
     // primitives, 1080p, 4 spp: 263 ms with 32 pixels per wave, 216 ms with 64) — as long as that leaves two waves
     // for every wave slot of the chip.
-    while (a.tile_log2 < 6 && ((uint32_t)cfg->n_samples << a.tile_log2) < 2048u && (a.n_lin >> (a.tile_log2 + 1)) >= 16384u) a.tile_log2++;
+    while (a.tile_log2 < 6 && ((uint32_t)sample_count << a.tile_log2) < 2048u && (a.n_lin >> (a.tile_log2 + 1)) >= 16384u) a.tile_log2++;
     if (sc->tune[PT_TUNE_TILE_LOG2] != 0) a.tile_log2 = sc->tune[PT_TUNE_TILE_LOG2];
     if (cfg->tile_log2 != 0) a.tile_log2 = cfg->tile_log2;
     a.fb_layout = cfg->fb_layout;
@@ -926,6 +935,58 @@ int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* strea
     if (cfg->math_mode == PT_MATH_FAST || cfg->math_mode == PT_MATH_FAST_SCALAR || cfg->math_mode == PT_MATH_FAST_LDS)
         return ptk_render_fast(a, cfg->math_mode, (hipStream_t)stream);
     return PT_FAIL("pt_render: unknown math_mode");
+}
+
+namespace {
+// p_color = totalLight / n_samples (main.cu:67) from the 32.32 sums, with the arithmetic of the render kernels' own
+// last step (ptw::from_fixed, then one float division), for the pixels of the rendered rows: one thread per pixel.
+__global__ void resolve_kernel(const unsigned long long* __restrict__ sums, float* __restrict__ fb, uint32_t n_lin, int max_x, int max_y,
+                               int row_begin, int row_step, int compact, int layout, float ns) {
+    const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lin >= n_lin) return;
+    const uint32_t k = lin / (uint32_t)max_x, i = lin - k * (uint32_t)max_x;
+    const size_t out = compact ? (size_t)lin : (size_t)(row_begin + (int)k * row_step) * (size_t)max_x + i;
+    const size_t plane = compact ? (size_t)n_lin : (size_t)max_x * (size_t)max_y;
+    for (int c = 0; c < 3; c++) {
+        const size_t at = layout == PT_FB_AOS ? out * 3u + (size_t)c : (size_t)c * plane + out;
+        const unsigned long long v = sums[at];
+        fb[at] = ((float)(int)(v >> 32) + (float)(unsigned)v * 2.3283064365386963e-10f) / ns;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* stream) {
+    if (!d_fb) return PT_FAIL("pt_render: null argument");
+    return render_launch(sc, cfg, d_fb, 0, cfg ? cfg->n_samples : 0, nullptr, stream);
+}
+
+int pt_render_samples(const pt_scene* sc, const pt_config* cfg, int sample_begin, int sample_count,
+                      unsigned long long* d_sums, void* stream) {
+    if (!d_sums) return PT_FAIL("pt_render_samples: null argument");
+    return render_launch(sc, cfg, nullptr, sample_begin, sample_count, d_sums, stream);
+}
+
+long long pt_sums_count(const pt_config* cfg) {
+    if (!cfg || cfg->max_x <= 0 || cfg->max_y <= 0 || cfg->row_begin < 0 || cfg->row_end > cfg->max_y || cfg->row_begin > cfg->row_end || cfg->row_step < 0) return -1;
+    const int step = cfg->row_step == 0 ? 1 : cfg->row_step;
+    const long long rows = cfg->fb_compact ? (cfg->row_end - cfg->row_begin + step - 1) / step : cfg->max_y;
+    return rows * cfg->max_x * 3;
+}
+
+int pt_resolve(const pt_scene* sc, const pt_config* cfg, const unsigned long long* d_sums, float* d_fb, void* stream) {
+    if (!sc || !cfg || !d_sums || !d_fb) return PT_FAIL("pt_resolve: null argument");
+    if (pt_sums_count(cfg) < 0 || cfg->n_samples <= 0) return PT_FAIL("pt_resolve: bad image size, rows or n_samples");
+    if (cfg->fb_layout != PT_FB_AOS && cfg->fb_layout != PT_FB_SOA) return PT_FAIL("pt_resolve: unknown fb_layout");
+    const int step = cfg->row_step == 0 ? 1 : cfg->row_step;
+    const uint32_t n_lin = (uint32_t)((cfg->row_end - cfg->row_begin + step - 1) / step) * (uint32_t)cfg->max_x;
+    if (n_lin == 0) return 0;
+    PT_CHECK(hipSetDevice(sc->device));
+    hipLaunchKernelGGL(resolve_kernel, dim3((n_lin + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, d_sums, d_fb, n_lin, cfg->max_x, cfg->max_y,
+                       cfg->row_begin, step, cfg->fb_compact, cfg->fb_layout, (float)cfg->n_samples);
+    PT_CHECK(hipGetLastError());
+    return 0;
 }
 
 int pt_raypath_batch(const pt_scene* sc, int prim, const float* d_o, const float* d_d, int n_rays, int filter,

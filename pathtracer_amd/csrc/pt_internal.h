@@ -194,8 +194,10 @@ struct RenderArgs {
     float p00[3];          // pixel00_loc
     float du, dv;          // pixel_delta_u.x, pixel_delta_v.y
     int32_t max_x, max_y;
-    int32_t n_samples, n_bounces;
-    float sample_cap;      // 2^30 / n_samples: what one sample's radiance counts as at most (pixel sums are 32.32 fixed point)
+    int32_t n_samples, n_bounces;   // n_samples: samples per pixel THIS launch traces, numbered sample_begin ... (RNG streams go by that number)
+    int32_t sample_begin;
+    unsigned long long* sums;       // null: the launch writes fb = sum / n_samples; else it ADDS its pixels' 32.32 sums here (pt_render_samples)
+    float sample_cap;      // 2^30 / (samples of the whole frame): what one sample's radiance counts as at most (pixel sums are 32.32 fixed point)
     int32_t bsdf_model;    // PT_BSDF_*
     uint32_t seed_hash;    // H(seed + 0x9E3779B9)
     int32_t row_begin, row_step, n_rows;   // rendered rows: row_begin + k*row_step, k in [0, n_rows)

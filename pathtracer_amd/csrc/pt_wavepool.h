@@ -83,7 +83,22 @@ __device__ __forceinline__ void add_sample(const WaveLds& l, uint32_t px, const 
 }
 
 // p_color = totalLight / n_samples (main.cu:67); consecutive floats of consecutive pixels leave together.
+// A launch that traces a range of the frame's samples adds its sums to the caller's instead (same slots, 64-bit
+// integers; atomically, so that launches on different streams may share the buffer).
 __device__ __forceinline__ void store_tile(const RenderArgs& a, const WaveLds& l, uint32_t npx, unsigned lane) {
+    if (a.sums != nullptr) {
+        if (a.fb_layout == PT_FB_AOS) {
+            for (uint32_t f = lane; f < npx * 3u; f += 64u) {
+                const uint32_t px = (f * 43691u) >> 17;
+                atomicAdd(&a.sums[(size_t)l.out_px[px] * 3u + (f - px * 3u)], l.acc[f]);
+            }
+        } else {
+            const size_t plane = a.fb_compact ? (size_t)a.n_lin : (size_t)a.max_x * (size_t)a.max_y;
+            if (lane < npx)
+                for (int c = 0; c < 3; c++) atomicAdd(&a.sums[c * plane + l.out_px[lane]], l.acc[lane * 3 + c]);
+        }
+        return;
+    }
     const float ns = (float)a.n_samples;
     if (a.fb_layout == PT_FB_AOS) {
         for (uint32_t f = lane; f < npx * 3u; f += 64u) {
@@ -142,7 +157,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, 
                     if (made >= total) break;
                     const uint32_t w = made + lane;
                     float4 ray;
-                    T::make_ray(a, ctx, w & (P - 1u), lin_base + (w & (P - 1u)), w >> lg, ray);
+                    T::make_ray(a, ctx, w & (P - 1u), lin_base + (w & (P - 1u)), (w >> lg) + (uint32_t)a.sample_begin, ray);
                     stash[w & 63u] = ray;
                     made = min(made + 64u, total);
                 }
@@ -223,7 +238,7 @@ __device__ __forceinline__ void render_tile_blocksync(const RenderArgs& a, uint3
             const uint32_t w = next + prefix_count(want);
             next += (uint32_t)__popcll(want);
             if (!active && w < total) {
-                const uint32_t px = w & (P - 1u), smp = w >> lg;
+                const uint32_t px = w & (P - 1u), smp = (w >> lg) + (uint32_t)a.sample_begin;
                 if (px < npx) {
                     my_px = px;
                     T::start(path, a, ctx, px, lin_base + px, smp);

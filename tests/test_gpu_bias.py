@@ -12,16 +12,17 @@ import tolerances as tol
 pytestmark = pytest.mark.gpu
 
 W, H, SPP, SEEDS = 128, 72, 16, 32
+SEEDS_SMALL_SHAPES = 512        # the 10 000-shape scene: until the noise of the mean is 0.015 % of the mean
 
 
-def _seed_averaged_difference(pt, scene, depth):
+def _seed_averaged_difference(pt, scene, depth, seeds=SEEDS):
     diffs = []
     par_mean = 0.0
-    for seed in range(SEEDS):
+    for seed in range(seeds):
         f = scene.render(pt.make_config(W, H, SPP, n_bounces=depth, seed=seed, math_mode=pt.PT_MATH_FAST)).double()
         p = scene.render(pt.make_config(W, H, SPP, n_bounces=depth, seed=seed, math_mode=pt.PT_MATH_PARITY)).double()
         diffs.append((f - p).cpu().numpy())
-        par_mean = par_mean + p.mean(dim=(0, 1)).cpu().numpy() / SEEDS
+        par_mean = par_mean + p.mean(dim=(0, 1)).cpu().numpy() / seeds
     return np.stack(diffs), par_mean
 
 
@@ -42,17 +43,20 @@ def test_fast_minus_parity_shrinks_with_the_number_of_seeds(pt, name, depth, gen
     small = name == "10 000 small shapes"
     scene = pt.Scene(*(pt.default_scene() if name == "default" else (pt.synthetic_scene(5000, 4989, 12345) if small else pt.glass_grid_scene(5))),
                      general_kinds=general)
-    d, par_mean = _seed_averaged_difference(pt, scene, depth)
-    rms, rel = _rms_by_group_size(d, par_mean)
+    d, par_mean = _seed_averaged_difference(pt, scene, depth, SEEDS_SMALL_SHAPES if small else SEEDS)
+    rms, rel = _rms_by_group_size(d[:SEEDS], par_mean)
     print("%s: RMS of the seed-averaged difference / mean radiance: %s" % (name, {s: "%.4f" % v for s, v in rel.items()}))
     assert rms[1] > 0.0                                                  # the two kernels do differ somewhere
     # one seed: branch-flip noise (small frame, depth 31: x3; shapes smaller than a pixel, whose every sample is a near miss: x12)
     assert rel[1] <= (12.0 if small else 3.0) * tol.fast_image_rmse(SPP)
     # noise law: each doubling of the seeds takes sqrt(2) off; a bias floor would stop the fall
     assert rms[32] <= 1.5 * rms[1] / np.sqrt(32.0), rel
-    bias = np.abs(d.mean(axis=(0, 1, 2))) / par_mean                     # per channel, all seeds and pixels
-    print("%s: per-channel mean of fast - parity over %d seeds, relative: %s" % (name, SEEDS, bias))
-    assert (bias <= tol.FAST["bias_mean_rel_small_shapes" if small else "bias_mean_rel"]).all(), bias
+    per_seed = d.mean(axis=(1, 2))                                       # the paired difference of the frame means, per seed and channel
+    bias = np.abs(per_seed.mean(axis=0)) / par_mean
+    err = per_seed.std(axis=0, ddof=1) / np.sqrt(len(per_seed)) / par_mean
+    print("%s: per-channel mean of fast - parity over %d seeds, relative: %s +- %s" % (name, len(per_seed), bias, err))
+    assert (bias <= tol.FAST["bias_mean_rel_small_shapes" if small else "bias_mean_rel"]).all(), (bias, err)
+    if small: assert (err <= 0.0003).all(), err                          # the measurement resolves the bound
 
 
 # History of the glass-grid case: uniformly scaled spheres used to be tested in world space (|o - centre|^2 - r^2).
@@ -63,8 +67,13 @@ def test_fast_minus_parity_shrinks_with_the_number_of_seeds(pt, name, depth, gen
 # an RMS floor of 3.4 % that no number of seeds removed.  The test above found it; the record kind now evaluates
 # o_l = k*o + q as the reference does, and the floor is gone (mean 0.03 %, within the noise of 32 seeds).
 #
-# The 10 000-shape case: spheres of diameter 0.01-0.03 up to 5 units away have their discriminant cancel to a few bits in
-# float, in the reference's frame as in any other, so a hit's position is off the surface by far more than the 1e-5
-# filter and what the next segment sees depends on how the test rounds.  The short sphere record gave +0.27 % in the mean
-# there; spheres that far out (|centre| / scale > 32) now keep the general record, whose operations are the reference's:
-# +0.05 % (red, blue), +0.2 % (green), with a noise of 0.09 % at this sample count.
+# The 10 000-shape case: spheres of diameter 0.01-0.03 up to 5 units away have their discriminant b*b - 4*a*c cancel to
+# a few bits in float.  The reference rounds the two products before it subtracts them, so for a band of rays that just
+# miss they come out equal, the discriminant is exactly 0 and shapes.h:337 counts a tangent hit: its small far spheres are
+# in effect a little larger than their radius.  A fused multiply-add has no such band, and with it the fast kernels
+# rendered this scene 0.12 % (red, green) / 0.07 % (blue) brighter than the parity-order kernel, in every class of pixels
+# (tools/bias_study.py, 1024 seeds, standard error 0.009 %).  Spheres that far out (|centre| / scale > 32) get the general
+# sphere record, which now rounds every product and sum as the reference does (test_sphere, take_quadratic<true>): the
+# difference is 0.002 / -0.005 / -0.005 % +- 0.009 over 768 seeds.  Which part carried it was found by giving the
+# parity-order kernel the fast kernels' habits one at a time: hit position as o + d*t no change, fused transforms no
+# change, fused discriminant half of it.
