@@ -29,6 +29,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -411,6 +412,8 @@ struct render_options {
     int bsdf_model = PT_BSDF_REFERENCE;   // PT_BSDF_CLASSES: tracePath of bsdf_alternative.h
     int tile_log2 = 0;           // log2 of the pixels per wave64 (2..6), 0 = chosen from the launch size
     int device = 0;
+    int spp_chunk = 0;           // > 0: the sample loop (main.cu:61-67) runs as launches of at most this many samples each,
+                                 // their exact sums kept in device memory between them; same image bit for bit
 };
 
 inline pt_config pt_make_config(const config_t& config, const render_options& opt) {
@@ -431,7 +434,21 @@ inline pt_config pt_make_config(const config_t& config, const render_options& op
 inline void render(vec3* fb, config_t config, const pt::DeviceScene& scene, const render_options& opt = render_options(), hipStream_t stream = nullptr) {
     static_assert(sizeof(vec3) == 12, "vec3 must be three packed floats");
     const pt_config c = pt_make_config(config, opt);
-    checkHipErrors(pt_render(scene.handle(), &c, reinterpret_cast<float*>(fb), stream));
+    if (opt.spp_chunk <= 0 || opt.spp_chunk >= c.n_samples) {
+        checkHipErrors(pt_render(scene.handle(), &c, reinterpret_cast<float*>(fb), stream));
+        return;
+    }
+    const long long n = pt_sums_count(&c);
+    if (n <= 0) return;
+    unsigned long long* sums = nullptr;
+    checkHipErrors(hipSetDevice(pt_scene_device(scene.handle())));
+    checkHipErrors(hipMalloc((void**)&sums, (size_t)n * sizeof(unsigned long long)));
+    checkHipErrors(hipMemsetAsync(sums, 0, (size_t)n * sizeof(unsigned long long), stream));
+    for (int s0 = 0; s0 < c.n_samples; s0 += opt.spp_chunk)
+        checkHipErrors(pt_render_samples(scene.handle(), &c, s0, std::min(opt.spp_chunk, c.n_samples - s0), sums, stream));
+    checkHipErrors(pt_resolve(scene.handle(), &c, sums, reinterpret_cast<float*>(fb), stream));
+    checkHipErrors(hipStreamSynchronize(stream));
+    checkHipErrors(hipFree(sums));
 }
 
 // The reference's launch shape: render(fb, config, scene, n_objects).

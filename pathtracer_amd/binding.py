@@ -77,6 +77,10 @@ def _load():
     L.pt_scene_device.argtypes = [vp]
     L.pt_scene_bvh_nodes.argtypes = [vp]
     L.pt_render.argtypes = [vp, C.POINTER(pt_config), vp, vp]
+    L.pt_render_samples.argtypes = [vp, C.POINTER(pt_config), i32, i32, vp, vp]
+    L.pt_sums_count.restype = C.c_longlong
+    L.pt_sums_count.argtypes = [C.POINTER(pt_config)]
+    L.pt_resolve.argtypes = [vp, C.POINTER(pt_config), vp, vp, vp]
     L.pt_raypath_batch.argtypes = [vp, i32, vp, vp, i32, i32] + [vp] * 9 + [vp]
     L.pt_nearest_batch.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.pt_nearest_batch_mode.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
@@ -110,7 +114,7 @@ lib = _load()
 
 EXPORTS = [
     "pt_scene_upload", "pt_scene_upload_opt", "pt_scene_tune", "pt_scene_free", "pt_scene_device", "pt_scene_bvh_nodes", "pt_default_scene", "pt_glass_grid_scene",
-    "pt_synthetic_scene", "pt_focal_length", "pt_render", "pt_raypath_batch", "pt_nearest_batch", "pt_nearest_batch_mode",
+    "pt_synthetic_scene", "pt_focal_length", "pt_render", "pt_render_samples", "pt_sums_count", "pt_resolve", "pt_raypath_batch", "pt_nearest_batch", "pt_nearest_batch_mode",
     "pt_trace_paths", "pt_trace_paths_alt", "pt_trace_paths_end", "pt_rng_draws", "pt_bsdf_batch", "pt_bsdf_arity", "pt_ppm_p3", "pt_last_error", "pt_version",
     "pt_scene_parse", "pt_ppm_p6", "pt_pfm",
     "pt_tile_rows", "pt_comm_unique_id", "pt_comm_init_rank", "pt_comm_init_all", "pt_comm_free", "pt_comm_rank",
@@ -282,6 +286,32 @@ class Scene:
         assert out.is_contiguous() and out.dtype == torch.float32 and out.numel() >= rows * cfg.max_x * 3
         with torch.cuda.device(self.device):
             _check(lib.pt_render(self.h, C.byref(cfg), _ptr(out), _stream()))
+        return out
+
+    def render_samples(self, cfg, sample_begin, sample_count, sums=None):
+        """pt_render_samples: adds the 32.32 sums of samples [sample_begin, sample_begin + sample_count) to `sums`
+        (an int64 device tensor of pt_sums_count(cfg) elements, made and zeroed here when None)."""
+        torch = _torch()
+        n = int(lib.pt_sums_count(C.byref(cfg)))
+        if n < 0:
+            raise PtError("pt_sums_count: bad image size or rows")
+        if sums is None:
+            sums = torch.zeros(n, dtype=torch.int64, device=self._dev())
+        assert sums.is_contiguous() and sums.dtype == torch.int64 and sums.numel() >= n
+        with torch.cuda.device(self.device):
+            _check(lib.pt_render_samples(self.h, C.byref(cfg), sample_begin, sample_count, _ptr(sums), _stream()))
+        return sums
+
+    def resolve(self, cfg, sums, out=None):
+        """pt_resolve: the float framebuffer of the rendered rows from the sums of all cfg.n_samples samples."""
+        torch = _torch()
+        rows = rendered_rows(cfg) if cfg.fb_compact else cfg.max_y
+        shape = (rows, cfg.max_x, 3) if cfg.fb_layout == PT_FB_AOS else (3, rows, cfg.max_x)
+        if out is None:
+            out = torch.zeros(shape, dtype=torch.float32, device=self._dev())
+        assert out.is_contiguous() and out.dtype == torch.float32 and out.numel() >= rows * cfg.max_x * 3
+        with torch.cuda.device(self.device):
+            _check(lib.pt_resolve(self.h, C.byref(cfg), _ptr(sums), _ptr(out), _stream()))
         return out
 
     def raypath(self, prim, o, d, filter=True):

@@ -126,6 +126,7 @@ int main(int argc, char** argv) {
         else if (a == "--height") ny = std::atoi(next());
         else if (a == "--spp") opt.n_samples = std::atoi(next());
         else if (a == "--depth") opt.n_bounces = std::atoi(next());
+        else if (a == "--spp-chunk") opt.spp_chunk = std::atoi(next());
         else if (a == "--seed") opt.seed = (unsigned)std::strtoul(next(), nullptr, 10);
         else if (a == "--math") opt.math_mode = std::string(next()) == "parity" ? PT_MATH_PARITY : PT_MATH_FAST;
         else if (a == "--bsdf") opt.bsdf_model = std::string(next()) == "classes" ? PT_BSDF_CLASSES : PT_BSDF_REFERENCE;

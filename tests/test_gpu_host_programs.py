@@ -75,6 +75,18 @@ def test_host_program_interleaved_tiles_and_alternative_bsdf():
     assert alt.returncode == 0 and alt.stdout == pt.pfm(img) and alt.stdout != one.stdout
 
 
+def test_host_program_sample_loop_in_pieces():
+    """--spp-chunk runs the sample loop (main.cu:61-67) as several launches whose exact sums stay in device memory; the
+    image is the single launch's, byte for byte, also with row sets on several tiles."""
+    args = ["--width", "120", "--height", "68", "--spp", "24", "--format", "pfm"]
+    whole = subprocess.run([_need("pathtracer")] + args, capture_output=True, timeout=120)
+    assert whole.returncode == 0, whole.stderr[-400:]
+    for extra in (["--spp-chunk", "7"], ["--spp-chunk", "8", "--tiles", "3"], ["--spp-chunk", "1", "--math", "fast"], ["--spp-chunk", "100"]):
+        r = subprocess.run([_need("pathtracer")] + args + extra, capture_output=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-400:]
+        assert r.stdout == whole.stdout, extra
+
+
 def test_host_program_rccl_gather_on_one_device():
     """--gather rccl: the tiles travel through pt_comm_init_all + pt_gather_framebuffer instead of per-tile host
     copies (one GPU here, so a communicator of one rank); same file."""
