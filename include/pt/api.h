@@ -105,20 +105,30 @@ inline pt_material to_abi(const Material& m) {
     return r;
 }
 
-// Staging memory of the calls below: one device buffer and one pinned host buffer per host thread, grown to the
-// largest request so far and kept (pt::release_cached() frees them).  A call packs its inputs at the front and reads
-// its outputs behind them: one copy in, the launch, one copy out.
+// Staging memory of the calls below: one device buffer and one pinned host buffer per host thread AND device, grown
+// to the largest request so far and kept (pt::release_cached() frees them, and so does the end of the thread).  A call
+// packs its inputs at the front and reads its outputs behind them: one copy in, the launch, one copy out.  The device
+// buffer lives on the device of the scene the call is for, whatever device is current.
 struct Staging {
+    int device = 0;
     char* dev = nullptr;
     char* host = nullptr;
     size_t cap = 0;
+    Staging() = default;
+    Staging(const Staging&) = delete;
+    Staging& operator=(const Staging&) = delete;
+    ~Staging() { release(); }
     void reserve(size_t bytes) {
         if (bytes <= cap) return;
         release();
         size_t want = 1 << 16;
         while (want < bytes) want <<= 1;
+        int before = 0;
+        checkHipErrors(hipGetDevice(&before));
+        checkHipErrors(hipSetDevice(device));
         checkHipErrors(hipMalloc((void**)&dev, want));
         checkHipErrors(hipHostMalloc((void**)&host, want, hipHostMallocDefault));
+        checkHipErrors(hipSetDevice(before));
         cap = want;
     }
     void release() {
@@ -127,7 +137,20 @@ struct Staging {
         dev = nullptr; host = nullptr; cap = 0;
     }
 };
-inline Staging& staging() { static thread_local Staging s; return s; }
+struct StagingSet {
+    std::vector<Staging*> per_device;
+    ~StagingSet() { clear(); }
+    Staging& of(int device) {
+        if (device < 0) device = 0;
+        if ((size_t)device >= per_device.size()) per_device.resize((size_t)device + 1, nullptr);
+        if (!per_device[(size_t)device]) { per_device[(size_t)device] = new Staging(); per_device[(size_t)device]->device = device; }
+        return *per_device[(size_t)device];
+    }
+    void clear() { for (Staging* s : per_device) delete s; per_device.clear(); }
+};
+inline StagingSet& staging_set() { static thread_local StagingSet s; return s; }
+// This thread's staging buffers on the device of `sc`.
+inline Staging& staging(const pt_scene* sc) { return staging_set().of(pt_scene_device(sc)); }
 
 // Carves arrays out of the staging buffers, device and host side by side.
 struct Carver {
@@ -187,11 +210,12 @@ struct SceneCache {
         return h;
     }
     void clear() { for (Entry& e : entries) pt_scene_free(e.h); entries.clear(); }
+    ~SceneCache() { clear(); }
 };
 inline SceneCache& scene_cache() { static thread_local SceneCache c; return c; }
 
 // Frees this thread's staging buffers and cached scenes (they are otherwise kept until the process ends).
-inline void release_cached() { staging().release(); scene_cache().clear(); }
+inline void release_cached() { staging_set().clear(); scene_cache().clear(); }
 
 }  // namespace pt
 
@@ -283,7 +307,7 @@ inline void Shape::getIntersections_batch(const ray* rays, int n, RayPath* out, 
     Shape* self = const_cast<Shape*>(this);
     pt_scene* sc = pt::scene_cache().get(&self, 1);
     const size_t N = (size_t)n;
-    pt::Carver c(pt::staging());
+    pt::Carver c(pt::staging(sc));
     const size_t o = c.take<float>(3 * N), d = c.take<float>(3 * N), in_end = c.at;
     const size_t cnt = c.take<int32_t>(N), h1 = c.take<int32_t>(N), h2 = c.take<int32_t>(N), t1 = c.take<float>(N), t2 = c.take<float>(N);
     const size_t p1 = c.take<float>(3 * N), p2 = c.take<float>(3 * N), n1 = c.take<float>(3 * N), n2 = c.take<float>(3 * N);
@@ -314,7 +338,7 @@ inline RayPath Shape::query(const ray& r, int filter) const {
 inline void pt_nearest_rays(const ray* rays, int n, pt_scene* sc, Shape* const* scene, IntersectionPoint* out) {
     if (n <= 0) return;
     const size_t N = (size_t)n;
-    pt::Carver c(pt::staging());
+    pt::Carver c(pt::staging(sc));
     const size_t o = c.take<float>(3 * N), d = c.take<float>(3 * N), in_end = c.at;
     const size_t prim = c.take<int32_t>(N), in = c.take<int32_t>(N), t = c.take<float>(N), p = c.take<float>(3 * N), nr = c.take<float>(3 * N);
     c.st.reserve(c.at);
@@ -353,7 +377,7 @@ inline IntersectionPoint getNearestIntersection(const ray& r, Shape** scene, int
 inline void pt_trace_rays(pt_scene* sc, const ray* rays, const pt_rng* s, int n, vec3* out, ray* end, int n_bounces, int math_mode, int bsdf_model) {
     if (n <= 0) return;
     const size_t N = (size_t)n;
-    pt::Carver c(pt::staging());
+    pt::Carver c(pt::staging(sc));
     const size_t o = c.take<float>(3 * N), d = c.take<float>(3 * N), px = c.take<uint32_t>(N), sm = c.take<uint32_t>(N), in_end = c.at;
     const size_t rgb = c.take<float>(3 * N), eo = c.take<float>(3 * N), ed = c.take<float>(3 * N);
     c.st.reserve(c.at);

@@ -143,6 +143,8 @@ int pt_comm_init_all(int world, const int* devices, pt_comm** out) {
     if (!devices || !out || world <= 0) return PT_FAIL("pt_comm_init_all: bad arguments");
     const Rccl* R = rccl();
     if (!R) return PT_FAIL("pt_comm_init_all: librccl.so.1 could not be loaded");
+    int before = 0;
+    PT_CHECK(hipGetDevice(&before));                  // (before anything exists that an error return would have to undo)
     std::vector<ncclComm_t> comms((size_t)world, nullptr);
     PT_RCCL(R->CommInitAll(comms.data(), world, devices));
     for (int r = 0; r < world; r++) {
@@ -156,8 +158,6 @@ int pt_comm_init_all(int world, const int* devices, pt_comm** out) {
         out[r] = c;
     }
     // each device's own address of the static staging array, resolved with that device current
-    int before = 0;
-    PT_CHECK(hipGetDevice(&before));
     for (int r = 0; r < world; r++) {
         hipError_t e = hipSetDevice(devices[r]);
         int rc = e == hipSuccess ? scratch_address(&out[r]->scratch) : pt_set_error((int)e, "hipSetDevice(devices[r])", __FILE__, __LINE__);
@@ -167,7 +167,9 @@ int pt_comm_init_all(int world, const int* devices, pt_comm** out) {
             return rc;
         }
     }
-    PT_CHECK(hipSetDevice(before));
+    // on success the caller owns out[0..world); failing to go back to the device that was current is not worth
+    // taking them away again
+    (void)hipSetDevice(before);
     return 0;
 }
 

@@ -64,7 +64,8 @@ __device__ __forceinline__ PixelRef pixel_of(const RenderArgs& a, uint32_t lin) 
 // samples of a pixel are, their sum stays inside the 32 integer bits.
 __device__ __forceinline__ unsigned long long to_fixed_in_range(float x) {      // |x| <= 2^30, not a NaN
     const float fl = __builtin_floorf(x);
-    const unsigned lo = (unsigned)((x - fl) * 4294967296.0f);
+    // (x - fl rounds to 1 for a tiny negative x; 2^32 is outside unsigned's range, so the fraction stops one float below)
+    const unsigned lo = (unsigned)__builtin_fminf((x - fl) * 4294967296.0f, 4294967040.0f);
     const int hi = (int)fl;
     return ((unsigned long long)(unsigned)hi << 32) | lo;
 }

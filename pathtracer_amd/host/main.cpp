@@ -1,9 +1,12 @@
 // pathtracer — the reference's host flow (main.cu:200-257) on MI355X: build the
 // scene with the Shape constructors, render through the C ABI, print the image as
-// ASCII PPM (P3) on stdout with scanline progress on stderr.  Every literal of
+// ASCII PPM (P3) on stdout with scanline progress on stderr.  The default scene is the
+// library's table of main.cu:73-195 (pt_default_scene); examples/reference_main.cpp is
+// the same flow with the reference's own constructScene body.  Every literal of
 // the reference's main() is a flag here whose default is that literal:
 //   --width 800 --height 800 --spp 2000 --depth 5 --seed 0 --math fast --bsdf reference|classes
 //   --scene default|glass[N]|synthetic  --scene-file FILE  --format p3|p6|pfm  --gpus 1  --stats
+//   --spp-chunk S: the sample loop as launches of at most S samples each (same image)
 //   --tiles T (default = gpus): the image is split into T interleaved row sets, set k rendered on GPU k % gpus
 //   --gather host|rccl: tiles copied to the host image one by one (default), or all-gathered between the GPUs with RCCL
 // Usage, as in the reference's readme:  pathtracer > out.ppm
@@ -20,78 +23,6 @@
 #include <vector>
 
 #include "../../include/pt/api.h"
-
-// constructScene (main.cu:71-198) as a host function: same transforms, same
-// materials, same eleven `new` expressions.
-static int constructScene(Shape** scene) {
-    Affine3f floor = IDENTITY;
-    floor.linear() = AngleAxisf(PI / 2, vec3(1, 0, 0)).toRotationMatrix();
-    floor.translation() = Translation3f(0.0, -1.0, 0.0).translation();
-    Affine3f back = IDENTITY;
-    back.translation() = Translation3f(0.0, 0, -5.0).translation();
-    Affine3f left = IDENTITY;
-    left.linear() = AngleAxisf(PI / 2, vec3(0, 1, 0)).toRotationMatrix();
-    left.translation() = Translation3f(-1.0, 0.0, -5.0).translation();
-    Affine3f right = IDENTITY;
-    right.linear() = AngleAxisf(-PI / 2, vec3(0, 1, 0)).toRotationMatrix();
-    right.translation() = Translation3f(1.0, 0.0, -5.0).translation();
-    Affine3f ceiling = IDENTITY;
-    ceiling.linear() = AngleAxisf(-PI / 2, vec3(1, 0, 0)).toRotationMatrix();
-    ceiling.translation() = Translation3f(0.0, 1.0, 0.0).translation();
-    Affine3f light = IDENTITY;
-    light.linear() = AngleAxisf(-PI / 2, vec3(1, 0, 0)).toRotationMatrix();
-    light.translation() = Translation3f(0.0, 0.97, -3.25).translation();
-    Affine3f tplane6 = IDENTITY;
-    tplane6.linear() = AngleAxisf(PI, vec3(0, 1, 0)).toRotationMatrix();
-    tplane6.translation() = Translation3f(0.0, 0.0, 7.0).translation();
-    Affine3f t5 = IDENTITY;
-    t5.translation() = Translation3f(0.0, -0.5, -3.0).translation();
-    t5.scale(0.4f);
-    Affine3f t6 = IDENTITY;
-    t6.translation() = Translation3f(0.6, -0.5, -3.0).translation();
-    t6.scale(0.4f);
-    Affine3f t7 = IDENTITY;
-    t7.translation() = Translation3f(-0.6, -0.5, -3.0).translation();
-    t7.scale(0.4f);
-    Affine3f t8 = IDENTITY;
-    t8.translation() = Translation3f(0.0f, -0.5f, -4.2f).translation();
-    t8.scale(vec3(2.5f, 0.3f, 0.5f));
-
-    Material light_material;
-    light_material.emissive = vec3(1.0f, 0.9f, 0.7f) * 20.0f;
-    Material base;
-    base.albedo = vec3(0.4f, 0.4f, 0.4f);
-    Material green;
-    green.albedo = vec3(0.0f, 1.0f, 0.0f);
-    Material red;
-    red.albedo = vec3(1.0f, 0.0f, 0.0f);
-    Material glass;
-    glass.f0 = 0.02f;
-    glass.specularRoughness = 0;
-    glass.specularColor = vec3(1.0f, 1.0f, 1.0f) * 0.8f;
-    glass.IOR = 1.5f;
-    glass.transparency = 1.0f;
-    glass.refractionRoughness = 0.0f;
-    glass.bsdfType = 1;
-    Material diffuse_pure;
-    diffuse_pure.albedo = vec3(0.6f, 0.6f, 0.6f);
-    Material glass1 = glass, glass2 = glass, glass3 = glass;
-    glass2.refractionColor = vec3(0.9f, 0.0f, 0.0f);
-    glass3.refractionColor = vec3(2.0f, 0.0f, 0.0f);
-
-    scene[0] = new Plane(base, floor, -15.0f, -15.0f, 15.0f, 15.0f);
-    scene[1] = new Plane(red, left, -15.0f, -15.0f, 15.0f, 15.0f);
-    scene[2] = new Plane(green, right, -15.0f, -15.0f, 15.0f, 15.0f);
-    scene[3] = new Plane(base, back, -15.0f, -15.0f, 15.0f, 15.0f);
-    scene[4] = new Plane(base, ceiling, -15.0f, -15.0f, 15.0f, 15.0f);
-    scene[5] = new Plane(light_material, light, -0.5f, -0.5f, 0.5f, 0.5f);
-    scene[6] = new Plane(base, tplane6, -15.0f, -15.0f, 15.0f, 15.0f);
-    scene[7] = new Sphere(glass1, t7);
-    scene[8] = new Sphere(glass2, t5);
-    scene[9] = new Sphere(glass3, t6);
-    scene[10] = new Cube(diffuse_pure, t8);
-    return 11;
-}
 
 // Shapes from a flat description (the library's glass-grid and synthetic builders).
 static int shapesFromTable(const std::vector<pt_prim>& prims, const std::vector<pt_material>& mats, std::vector<Shape*>& scene) {
@@ -162,14 +93,14 @@ int main(int argc, char** argv) {
         if (n <= 0) { std::cerr << (n < 0 ? pt_last_error() : "scene file has no shapes") << "\n"; return 2; }
         prims.resize((size_t)n);
         shapesFromTable(prims, mats, scene);
-    } else if (scene_name == "default") {
-        scene.resize(11);
-        constructScene(scene.data());
     } else {
         std::vector<pt_prim> prims;
         std::vector<pt_material> mats(8);
         int nm = 0, n = 0;
-        if (scene_name.rfind("glass", 0) == 0) {
+        if (scene_name == "default") {
+            prims.resize(11);
+            n = pt_default_scene(prims.data(), mats.data(), &nm);
+        } else if (scene_name.rfind("glass", 0) == 0) {
             const int g = scene_name.size() > 5 ? std::atoi(scene_name.c_str() + 5) : 5;
             prims.resize(8 + (size_t)g * g);
             n = pt_glass_grid_scene(g, prims.data(), mats.data(), &nm);

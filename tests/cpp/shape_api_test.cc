@@ -159,6 +159,34 @@ TEST(ApiTest, TracePathLeavesItsLastRayInR) {
     }
 }
 
+TEST(ApiTest, StagingFollowsTheDeviceOfTheScene) {
+    // The one-ray calls use device 0; a batch call with a scene on another device must stage on THAT device.  With
+    // one GPU the second device is device 0 again and the test still walks the interleaved order.
+    int n_dev = 0;
+    checkHipErrors(hipGetDeviceCount(&n_dev));
+    const int other = n_dev >= 2 ? 1 : 0;
+    if (n_dev < 2) std::printf("           (one GPU visible: both scenes on device 0)\n");
+    Material white; white.albedo = vec3(1.0f, 1.0f, 1.0f);
+    Affine3f t = IDENTITY; t.translation() = vec3(0, 0, -3);
+    Shape* scene[1] = {new Plane(white, t)};
+    ray r(vec3(0, 0, 0), vec3(0, 0, -1));
+    pt::DeviceScene far_scene(scene, 1, other);
+    for (int round = 0; round < 3; round++) {
+        IntersectionPoint a = getNearestIntersection(r, scene, 1);              // device 0, cached scene
+        IntersectionPoint b;
+        getNearestIntersection_batch(&r, 1, far_scene, scene, &b);               // the other device
+        EXPECT_EQ(a.intersects, true); EXPECT_EQ(b.intersects, true);
+        EXPECT_EQ(a.distance, 3.0f); EXPECT_EQ(b.distance, 3.0f);
+        pt_rng s;
+        vec3 c;
+        tracePath_batch(far_scene, &r, &s, 1, &c);
+        EXPECT_EQ(c.x(), 0.0f);
+    }
+    checkHipErrors(hipSetDevice(0));
+    pt::release_cached();
+    delete scene[0];
+}
+
 TEST(ApiTest, UnusedAliasesOfVecMathExist) {                              // vec_math.h:15-17
     vec4 v(1, 2, 3, 4);
     matrix4 m = matrix4::Identity();

@@ -23,7 +23,7 @@ def test_reference_shape_tests_through_the_cpp_api():
     r = subprocess.run([_need("shape_api_test")], capture_output=True, text=True, timeout=120)
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "5 test(s), 0 failure(s)" in r.stdout
+    assert "6 test(s), 0 failure(s)" in r.stdout
 
 
 def test_host_program_matches_library_render_and_reference_ppm_format():
@@ -39,6 +39,17 @@ def test_host_program_matches_library_render_and_reference_ppm_format():
     assert r.stdout == pt.ppm_p3(img)
     head = r.stdout.split(b"\n", 3)[:3]
     assert head == [b"P3", b"96 64", b"255"]
+
+
+def test_reference_main_example_prints_the_same_file():
+    """examples/reference_main.cpp keeps the reference's constructScene body and main() flow (main.cu:71-257) on the
+    source-level API; the product's program takes its default scene from pt_default_scene.  Same scene, same file."""
+    exe = os.path.join(ROOT, "examples", "reference_main")
+    assert os.path.exists(exe), "%s is not built; run __graft_entry__.build()" % exe
+    a = subprocess.run([exe, "96", "64", "8"], capture_output=True, timeout=120)
+    b = subprocess.run([_need("pathtracer"), "--width", "96", "--height", "64", "--spp", "8"], capture_output=True, timeout=120)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr[-300:] + b.stderr[-300:]
+    assert a.stdout == b.stdout and a.stdout.startswith(b"P3\n96 64\n255\n")
 
 
 def test_host_program_rejects_bad_arguments():

@@ -27,8 +27,8 @@ FAST = {
     "nearest_prim_mismatch": 5e-3,  # rays naming another primitive (measured 2e-3): re-hits of the surface a grazing ray
     "rehit_t": 1e-2,                # leaves, at a distance below rehit_t, ties within t_rel_max, and
     "nearest_grazing": 5e-4,        # grazing hits of small shapes (measured: 1 ray of 4096 on the 10 000-primitive scene)
-    "image_rmse_at_1spp": 0.16,   # fast_image_rmse(spp) = this / sqrt(spp); measured x sqrt(spp): 0.086 (256x256@16, 2.1 %),
-                                  # 0.110 (1080p@64, 1.37 %), 0.085 (every 400th row of 4K@1024, 0.27 %)
+    "image_rmse_at_1spp": 0.13,   # fast_image_rmse(spp) = this / sqrt(spp); measured x sqrt(spp): 0.086 (256x256@16, 2.1 %),
+                                  # 0.097 (1080p@64, 1.21 %), 0.086 (every 400th row of 4K@1024, 0.27 %)
     "bad_pixel_frac": 3e-3,       # measured 1.0e-3 at 1080p@64
     "mean_rel": 0.005,            # per-channel mean radiance of one frame (converged-statistics bound)
     "bias_mean_rel": 0.001,       # per-channel mean of the seed-averaged difference to the parity-order kernel
@@ -50,7 +50,7 @@ FAST = {
 # coordinate: 3.3e-5 default, 2.2e-4 small shapes; normals (99th percentile, per component): 7.7e-6 and 1.8e-3 (a
 # position error divided by the radius).
 FAST_NEAREST = {
-    "default": {"t_ulp_median": 1, "t_ulp_p99": 64, "t_ulp_max": 1024, "pos_rel_max": 1e-4, "nrm_abs_p99": 1e-4},
+    "default": {"t_ulp_median": 1, "t_ulp_p99": 64, "t_ulp_max": 512, "pos_rel_max": 1e-4, "nrm_abs_p99": 1e-4},
     "any": {"t_ulp_median": 2, "t_ulp_p99": 1024, "t_ulp_max": 8192, "pos_rel_max": 1e-3, "nrm_abs_p99": 1e-2},
 }
 
@@ -58,7 +58,7 @@ FAST_NEAREST = {
 # quantities).
 GLASS_DEPTH_31 = {       # 5x5 glass spheres, 32 segments, 160x90@16: almost every path crosses several refractions
     "parity_image_rmse": 0.02, "parity_bad_pixel_frac": 0.002,
-    "fast_image_rmse": 0.2, "fast_bad_pixel_frac": 0.02, "fast_mean_rel": 0.02,
+    "fast_image_rmse": 0.17, "fast_bad_pixel_frac": 0.02, "fast_mean_rel": 0.02,     # measured 0.111 / 0.0076
 }
 MANY_SMALL_SHAPES = {"fast_bad_pixel_frac": 0.02}      # 10 000 primitives / 73 primitives with 41 materials, small frames
 CLASSES_BSDF = {"fast_bad_pixel_frac": 0.02, "fast_mean_rel": 0.03}   # bsdf_alternative.h model; parity unpinned (no reference output)
