@@ -46,7 +46,7 @@ def flops_per_sample():
         return float(json.load(f)[FLOPS_KEY]["flops_per_sample"])
 
 
-STORED_COUNTERS = os.path.join("profiles", "r02", "pmc_config2.json")
+STORED_COUNTERS = os.path.join("profiles", "r03", "pmc_config2.json")
 
 
 def stored_counters(kernel, kernel_ms):
@@ -55,8 +55,9 @@ def stored_counters(kernel, kernel_ms):
     FETCH_SIZE, in KB; the gfx950 fetch counter reports half the bytes of wide reads), the FP32 rate the hardware
     executed (issue slots of FMA x 2 + MUL + ADD + TRANS, x 64 lanes), the vector issue rate beside the
     microbenchmark's rate for the same mix, lane utilisation and occupancy.  The counters are NOT collected by this
-    run: they go stale when the kernel changes, which is why the source file and its kernel name are in the line.
-    None when no pass of that kernel is stored."""
+    run.  The stored file carries a hash of the kernels' sources and compiler flags (tools/pmc_summary.py:
+    kernel_source_hash, written when the passes are collected): None when it is not today's hash, or when no pass of
+    that kernel is stored — a stale block drops out of the line instead of describing another kernel."""
     path = os.path.join(ROOT, STORED_COUNTERS)
     if not os.path.exists(path):
         return None
@@ -64,10 +65,10 @@ def stored_counters(kernel, kernel_ms):
     import pmc_summary
     with open(path) as f:
         pmc = json.load(f)
-    if kernel not in pmc.get("profiled_kernel", ""):
+    if kernel not in pmc.get("profiled_kernel", "") or pmc.get("source_hash") != pmc_summary.kernel_source_hash():
         return None
     d = pmc_summary.derive(pmc, kernel_ms)
-    return {"source": STORED_COUNTERS + " (stored counter passes, not collected by this run)",
+    return {"source": STORED_COUNTERS + " (stored counter passes of these kernel sources, hash %s; not collected by this run)" % pmc["source_hash"],
             "traffic": d["hbm_bytes"], "executed_tflops": d["executed_tflops"], "executed_frac": d["executed_frac"],
             "executed_tflops_active_lanes": d["executed_tflops_active_lanes"],
             "valu_issue_rate": d["valu_issue_rate"], "valu_issue_ceiling": d["valu_issue_ceiling"],
@@ -157,6 +158,9 @@ def main():
     ap.add_argument("--general-kinds", action="store_true",
                     help="upload the scene with the general record kinds only (what a scene with rotated shapes gets); not the headline")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: gather each frame before rendering the next")
+    ap.add_argument("--gather", choices=["torch", "abi"], default="torch",
+                    help="N > 1: torch's all_gather_into_tensor + strided copy (default), or the C ABI's own collective "
+                         "(pt_comm_init_rank + pt_gather_framebuffer), its id handed out through the torch process group")
     ap.add_argument("--tile-log2", type=int, default=-1, help="pixels per wave as a power of two (development aid; default: this script's choice)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="development aid on one GPU: render rank 0's share of an N-GPU run with the N-GPU pipeline, no collectives")
@@ -216,7 +220,13 @@ def main():
         tile_log2 = args.tile_log2
     cfg = pt.make_config(WIDTH, HEIGHT, SPP, n_bounces=DEPTH, seed=SEED, row_begin=rank, row_end=HEIGHT, row_step=part,
                          fb_compact=1, math_mode=math_mode, tile_log2=tile_log2)
-    frames = [multigpu.TiledFrame(HEIGHT, WIDTH, part, device, collective=not emulate) for _ in range(2 if overlap else 1)]
+    comm = None
+    if args.gather == "abi" and world > 1:
+        if rehearse:
+            raise SystemExit("bench.py: --gather abi needs one GPU per rank (RCCL refuses two ranks on one device)")
+        comm = pt.Comm(multigpu.exchange_comm_id(rank, pt.comm_unique_id), rank, world, device=local_rank)
+        note("pt_comm ready")
+    frames = [multigpu.TiledFrame(HEIGHT, WIDTH, part, device, collective=not emulate, comm=comm) for _ in range(2 if overlap else 1)]
     main_stream = torch.cuda.current_stream()
     comm_stream = torch.cuda.Stream(device=device) if overlap else None
     # With frames in flight, consecutive frames render on alternating streams: the next frame's first waves fill
@@ -277,6 +287,7 @@ def main():
 
     # One frame at a time (render, then gather, nothing in flight beside it): what a single frame costs end to end.
     single_ms = None
+    gather_ms = None
     bitwise = None
     if part > 1:
         n_single = max(1, min(args.steps, 10))
@@ -285,13 +296,17 @@ def main():
                                     fb_compact=1, math_mode=math_mode)      # tile size: the library's choice for a lone launch
         fence()
         ts = time.perf_counter()
-        for _ in range(n_single):
+        gev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_single)]
+        for i in range(n_single):
             if my_rows:
                 scene.render(cfg_single, out=f0.local)
+            gev[i][0].record()
             f0.gather()
+            gev[i][1].record()
             torch.cuda.synchronize()
         fence()
         single_ms = (time.perf_counter() - ts) / n_single * 1e3
+        gather_ms = sum(a.elapsed_time(b) for a, b in gev) / n_single     # collective + reordering, on the device
         note("single frames done")
     if world > 1:
         # Rank 0 renders the whole frame alone (untimed) and compares the gathered image with it, bit for bit.
@@ -303,12 +318,12 @@ def main():
         bitwise = bool(int(flag[0]))
         note("bitwise check done")
 
-    t = torch.tensor([elapsed, kernel_ms, single_ms or 0.0], dtype=torch.float64, device="cpu" if rehearse else device)
+    t = torch.tensor([elapsed, kernel_ms, single_ms or 0.0, gather_ms or 0.0], dtype=torch.float64, device="cpu" if rehearse else device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = float(t[0]), float(t[1])
     if single_ms is not None:
-        single_ms = float(t[2])
+        single_ms, gather_ms = float(t[2]), float(t[3])
 
     if rank == 0:
         total_samples = WIDTH * HEIGHT * SPP
@@ -351,10 +366,15 @@ def main():
             out["pipelined"] = bool(overlap)
             out["frames_in_flight"] = len(frames)
             out["single_frame_ms"] = single_ms
+            out["gather"] = "pt_gather_framebuffer (C ABI: ncclAllGather + reordering kernel)" if comm is not None else "torch all_gather_into_tensor + strided copy"
+            out["gather_ms"] = gather_ms
             out["bitwise_equal_to_single_gpu"] = bitwise
         if world == 1 and not emulate and not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity_vs_oracle"] = cpu_baseline(image)
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -23,11 +23,25 @@ def rank_rows(height, rank, world):
     return range(rank, height, world)
 
 
-class TiledFrame:
-    """Buffers of one frame in flight: the local compact tile, the gathered tiles and the assembled image."""
+def exchange_comm_id(rank, make_id, group=None):
+    """The id of the library's own RCCL communicator (pt_comm_unique_id), made by rank 0 with `make_id()` and handed
+    to every rank through the torch process group that is already up (one broadcast of 128 bytes; gloo or nccl).
+    Every rank then calls pt_comm_init_rank with it (binding.Comm)."""
+    box = [make_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    ident = bytes(box[0])
+    assert len(ident) == 128, len(ident)
+    return ident
 
-    def __init__(self, height, width, world, device, collective=True):
+
+class TiledFrame:
+    """Buffers of one frame in flight: the local compact tile, the gathered tiles and the assembled image.
+    comm: a binding.Comm — the gather then goes through the C ABI (pt_gather_framebuffer: ncclAllGather + the
+    library's reordering kernel on the current stream) instead of torch's all_gather_into_tensor + strided copy."""
+
+    def __init__(self, height, width, world, device, collective=True, comm=None):
         self.height, self.width, self.world = height, width, world
+        self.comm = comm
         self.collective = collective     # False: development runs of one rank's pipeline without a process group
         self.rows = tile_rows(height, world)
         self.local = torch.zeros((self.rows, width, 3), dtype=torch.float32, device=device)
@@ -42,6 +56,8 @@ class TiledFrame:
         """All-gather the local tiles and put the rows back in image order."""
         if self.world == 1:
             return self.image
+        if self.comm is not None:
+            return self.comm.gather(self.local, self.gathered, self.image, self.height, self.width)
         if self.collective and self.local.is_cuda and dist.get_backend(group) == "gloo":
             # rehearsals of the N-rank flow on a box with one GPU: the gather goes through host memory
             host = torch.empty(self.gathered.numel(), dtype=torch.float32)

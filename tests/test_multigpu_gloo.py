@@ -78,3 +78,42 @@ def test_single_rank_frame_is_the_local_tile():
     f = multigpu.TiledFrame(5, 4, 1, "cpu")
     f.local[:] = 1.0
     assert f.gather() is f.image and f.image.shape == (5, 4, 3) and bool((f.image == 1.0).all())
+
+
+def _id_worker(rank, world, port, q):
+    for p in (ROOT,):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from pathtracer_amd import multigpu
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def make_id():                       # stands in for pt_comm_unique_id (ncclGetUniqueId): 128 opaque bytes
+        calls.append(rank)
+        return bytes((7 * k + 3) % 256 for k in range(128))
+    ident = multigpu.exchange_comm_id(rank, make_id)
+    q.put((rank, ident, list(calls)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_comm_id_made_by_rank_0_reaches_every_rank():
+    """`bench.py --gather abi` and any one-process-per-GPU host: rank 0 makes the id of the library's own RCCL
+    communicator and the process group that is already up hands it to the others; only rank 0 makes one."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_id_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = bytes((7 * k + 3) % 256 for k in range(128))
+    for rank, ident, calls in got:
+        assert ident == want, rank
+        assert calls == ([0] if rank == 0 else []), (rank, calls)

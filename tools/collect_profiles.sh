@@ -2,7 +2,7 @@
 # Collects, on the GPU box, everything a profiles/rNN/ directory holds: the benchmark line, rocprofv3 kernel statistics
 # and the five counter passes for the headline frame, the glass-grid depth-31 frame, the 10 000-primitive frame and
 # the headline frame with general record kinds only.  Every GPU step has its own time limit and the script stops at
-# the first failure.  Usage (repo root on the GPU box):  bash tools/collect_profiles.sh gpurun_out/r02
+# the first failure.  Usage (repo root on the GPU box):  bash tools/collect_profiles.sh gpurun_out/r03
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$1

@@ -7,9 +7,29 @@ of derive() when a kernel time is given.
 """
 import csv
 import glob
+import hashlib
 import json
 import os
+import re
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_SOURCES = ["pt_kernels_fast.hip", "pt_batched.h", "pt_wavepool.h", "pt_internal.h"]
+
+
+def kernel_source_hash():
+    """What the fast render kernels are compiled from: the sources and the compiler flags of the Makefile.  Counter
+    passes carry this hash; a reader that finds another one knows the passes belong to older kernels."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "pathtracer_amd", "csrc")
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    with open(os.path.join(csrc, "Makefile")) as f:
+        for line in f:
+            if re.match(r"^(COMMON|NOCOPY|FASTFLAGS|ARCH)\s*\??=", line):
+                h.update(line.strip().encode())
+    return h.hexdigest()[:16]
 
 N_SIMD = 1024                 # 256 compute units x 4
 WAVES_PER_SIMD = 8
@@ -75,6 +95,7 @@ def summarise(root, kernel):
         n = max(1, len(disp))
         out[pass_name] = {"dispatches": len(disp), "per_dispatch": {k: v / n for k, v in sorted(sums.items())}}
     out["profiled_kernel"] = "; ".join(sorted(names))
+    out["source_hash"] = kernel_source_hash()
     return out
 
 

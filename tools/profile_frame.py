@@ -6,7 +6,8 @@ its own beyond one line).  The scenes are the ones the benchmark configurations 
     python3 tools/profile_frame.py synthetic 1920 1080 4 5            # 10 000 primitives (hierarchy walk)
     python3 tools/profile_frame.py default  1920 1080 64 5 general    # general record kinds only (a rotated scene's cost)
 
-Optional trailing words: `general` (general_kinds = all), `parity` (parity math), `reps=N` (default 4).
+Optional trailing words: `general` (general_kinds = all), `parity` / `scalar` / `lds` (math mode; default fast),
+`nobvh` (no hierarchy: PT_MATH_FAST then runs its typed loops over every primitive), `reps=N` (default 4).
 """
 import os
 import sys
@@ -35,8 +36,8 @@ def main():
         if x.startswith("reps="):
             reps = int(x[5:])
     general = pt.PT_GENERAL_ALL if "general" in words else 0
-    mode = pt.PT_MATH_PARITY if "parity" in words else pt.PT_MATH_FAST
-    sc = pt.Scene(*get_scene(name), general_kinds=general)
+    mode = pt.PT_MATH_PARITY if "parity" in words else (pt.PT_MATH_FAST_SCALAR if "scalar" in words else (pt.PT_MATH_FAST_LDS if "lds" in words else pt.PT_MATH_FAST))
+    sc = pt.Scene(*get_scene(name), general_kinds=general, bvh_min_prims=(1 << 30) if "nobvh" in words else 0)
     cfg = pt.make_config(w, h, spp, n_bounces=depth, math_mode=mode)
     out = sc.render(cfg)
     torch.cuda.synchronize()
@@ -49,7 +50,7 @@ def main():
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     print("%s %s %dx%d@%d depth %d general=%d: min %.3f ms mean %.3f ms, %.1f Msamples/s, image mean %s" % (
-        name, "parity" if mode == pt.PT_MATH_PARITY else "fast", w, h, spp, depth, general, min(ts), sum(ts) / len(ts),
+        name, {pt.PT_MATH_PARITY: "parity", pt.PT_MATH_FAST: "fast", pt.PT_MATH_FAST_SCALAR: "fast_scalar", pt.PT_MATH_FAST_LDS: "fast_lds"}[mode] + (" nobvh" if "nobvh" in words else ""), w, h, spp, depth, general, min(ts), sum(ts) / len(ts),
         w * h * spp / min(ts) / 1e3, [round(x, 5) for x in out.mean(dim=(0, 1)).tolist()]), flush=True)
 
 
