@@ -7,7 +7,8 @@ its own beyond one line).  The scenes are the ones the benchmark configurations 
     python3 tools/profile_frame.py default  1920 1080 64 5 general    # general record kinds only (a rotated scene's cost)
 
 Optional trailing words: `general` (general_kinds = all), `parity` / `scalar` / `lds` (math mode; default fast),
-`nobvh` (no hierarchy: PT_MATH_FAST then runs its typed loops over every primitive), `reps=N` (default 4).
+`nobvh` (no hierarchy: PT_MATH_FAST then runs its typed loops over every primitive), `tune=KNOB:VALUE` (pt_scene_tune,
+may repeat), `reps=N` (default 4).
 """
 import os
 import sys
@@ -38,6 +39,10 @@ def main():
     general = pt.PT_GENERAL_ALL if "general" in words else 0
     mode = pt.PT_MATH_PARITY if "parity" in words else (pt.PT_MATH_FAST_SCALAR if "scalar" in words else (pt.PT_MATH_FAST_LDS if "lds" in words else pt.PT_MATH_FAST))
     sc = pt.Scene(*get_scene(name), general_kinds=general, bvh_min_prims=(1 << 30) if "nobvh" in words else 0)
+    for x in words:
+        if x.startswith("tune="):
+            k, v = x[5:].split(":")
+            sc.tune(int(k), int(v))
     cfg = pt.make_config(w, h, spp, n_bounces=depth, math_mode=mode)
     out = sc.render(cfg)
     torch.cuda.synchronize()

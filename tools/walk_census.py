@@ -1,18 +1,21 @@
 """Where the lanes are during the hierarchy walk (development aid).  Needs a library built with -DPT_WALK_CENSUS:
-    python tools/walk_census.py pathtracer_amd/libpt_hip_census.so [spp]"""
+    python tools/walk_census.py pathtracer_amd/libpt_hip_census.so [spp] [knob=value ...]     (pt_scene_tune knobs)"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from pathtracer_amd import binding as b
 L = C.CDLL(os.path.join(ROOT, sys.argv[1]))
-for name in ("pt_scene_upload", "pt_render", "pt_scene_free"):
+for name in ("pt_scene_upload", "pt_render", "pt_scene_free", "pt_scene_tune"):
     getattr(L, name).argtypes = getattr(b.lib, name).argtypes
 L.pt_dev_walk_census.argtypes = [C.c_void_p, C.c_int]
 prims, n, mats, nm = b.synthetic_scene(5000, 4989, 12345)
 h = C.c_void_p()
 assert L.pt_scene_upload(prims, n, mats, nm, 0, C.byref(h)) == 0
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+for kv in sys.argv[3:]:
+    k, v = kv.split("=")
+    assert L.pt_scene_tune(h, int(k), int(v)) == 0
 cfg = b.make_config(1920, 1080, spp)
 fb = torch.zeros((1080, 1920, 3), device="cuda")
 buf = (C.c_ulonglong * 8)()
