@@ -436,6 +436,7 @@ struct render_options {
     int bsdf_model = PT_BSDF_REFERENCE;   // PT_BSDF_CLASSES: tracePath of bsdf_alternative.h
     int tile_log2 = 0;           // log2 of the pixels per wave64 (2..6), 0 = chosen from the launch size
     int device = 0;
+    unsigned long long* d_counters = nullptr;   // device memory for PT_COUNTER_COUNT counters the render adds to (pt_render_counted), or null
     int spp_chunk = 0;           // > 0: the sample loop (main.cu:61-67) runs as launches of at most this many samples each,
                                  // their exact sums kept in device memory between them; same image bit for bit
 };
@@ -459,7 +460,8 @@ inline void render(vec3* fb, config_t config, const pt::DeviceScene& scene, cons
     static_assert(sizeof(vec3) == 12, "vec3 must be three packed floats");
     const pt_config c = pt_make_config(config, opt);
     if (opt.spp_chunk <= 0 || opt.spp_chunk >= c.n_samples) {
-        checkHipErrors(pt_render(scene.handle(), &c, reinterpret_cast<float*>(fb), stream));
+        if (opt.d_counters) checkHipErrors(pt_render_counted(scene.handle(), &c, reinterpret_cast<float*>(fb), opt.d_counters, stream));
+        else checkHipErrors(pt_render(scene.handle(), &c, reinterpret_cast<float*>(fb), stream));
         return;
     }
     const long long n = pt_sums_count(&c);

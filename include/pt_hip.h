@@ -180,6 +180,13 @@ float pt_focal_length(int nx, int ny, float v_height, float fov_deg);
  * refused.  n_samples is at most 2^24, n_bounces below 2^24. */
 int pt_render(const pt_scene* scene, const pt_config* cfg, float* d_fb, void* stream);
 
+/* pt_render that also counts what it traced: every wave ADDS to d_counters (PT_COUNTER_COUNT 64-bit integers on the
+ * scene's device, zeroed by the caller): [PT_COUNTER_SEGMENTS] path segments, i.e. calls of getNearestIntersection
+ * (bsdf.h:81).  Same image.  For run statistics (segments per sample, an estimate of the arithmetic done); the
+ * reference has no counterpart. */
+enum { PT_COUNTER_SEGMENTS = 0, PT_COUNTER_COUNT = 4 };
+int pt_render_counted(const pt_scene* scene, const pt_config* cfg, float* d_fb, unsigned long long* d_counters, void* stream);
+
 /* The sample loop of main.cu:61-67 in pieces.  pt_render_samples traces samples [sample_begin, sample_begin +
  * sample_count) of the cfg->n_samples that make up the frame (sample s of a pixel draws from the same random stream
  * whichever call traces it) and ADDS each pixel's sum of radiance, as signed 32.32 fixed point, to d_sums: 64-bit

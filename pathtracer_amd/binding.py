@@ -77,6 +77,7 @@ def _load():
     L.pt_scene_device.argtypes = [vp]
     L.pt_scene_bvh_nodes.argtypes = [vp]
     L.pt_render.argtypes = [vp, C.POINTER(pt_config), vp, vp]
+    L.pt_render_counted.argtypes = [vp, C.POINTER(pt_config), vp, vp, vp]
     L.pt_render_samples.argtypes = [vp, C.POINTER(pt_config), i32, i32, vp, vp]
     L.pt_sums_count.restype = C.c_longlong
     L.pt_sums_count.argtypes = [C.POINTER(pt_config)]
@@ -114,7 +115,7 @@ lib = _load()
 
 EXPORTS = [
     "pt_scene_upload", "pt_scene_upload_opt", "pt_scene_tune", "pt_scene_free", "pt_scene_device", "pt_scene_bvh_nodes", "pt_default_scene", "pt_glass_grid_scene",
-    "pt_synthetic_scene", "pt_focal_length", "pt_render", "pt_render_samples", "pt_sums_count", "pt_resolve", "pt_raypath_batch", "pt_nearest_batch", "pt_nearest_batch_mode",
+    "pt_synthetic_scene", "pt_focal_length", "pt_render", "pt_render_counted", "pt_render_samples", "pt_sums_count", "pt_resolve", "pt_raypath_batch", "pt_nearest_batch", "pt_nearest_batch_mode",
     "pt_trace_paths", "pt_trace_paths_alt", "pt_trace_paths_end", "pt_rng_draws", "pt_bsdf_batch", "pt_bsdf_arity", "pt_ppm_p3", "pt_last_error", "pt_version",
     "pt_scene_parse", "pt_ppm_p6", "pt_pfm",
     "pt_tile_rows", "pt_comm_unique_id", "pt_comm_init_rank", "pt_comm_init_all", "pt_comm_free", "pt_comm_rank",
@@ -287,6 +288,18 @@ class Scene:
         with torch.cuda.device(self.device):
             _check(lib.pt_render(self.h, C.byref(cfg), _ptr(out), _stream()))
         return out
+
+    def render_counted(self, cfg, out=None):
+        """pt_render_counted: (image, counters) — counters[0] = path segments traced (int64 device tensor of 4)."""
+        torch = _torch()
+        rows = rendered_rows(cfg) if cfg.fb_compact else cfg.max_y
+        shape = (rows, cfg.max_x, 3) if cfg.fb_layout == PT_FB_AOS else (3, rows, cfg.max_x)
+        if out is None:
+            out = torch.zeros(shape, dtype=torch.float32, device=self._dev())
+        counters = torch.zeros(4, dtype=torch.int64, device=self._dev())
+        with torch.cuda.device(self.device):
+            _check(lib.pt_render_counted(self.h, C.byref(cfg), _ptr(out), _ptr(counters), _stream()))
+        return out, counters
 
     def render_samples(self, cfg, sample_begin, sample_count, sums=None):
         """pt_render_samples: adds the 32.32 sums of samples [sample_begin, sample_begin + sample_count) to `sums`

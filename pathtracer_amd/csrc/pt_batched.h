@@ -153,7 +153,7 @@ PTB unsigned long long tile_candidates(const RenderArgs& a, const float* boxes, 
 // roulette.  What goes on is parked in L.stash, packed from entry 0; returns the number of entries.
 template <class X>
 PTB uint32_t camera_batch(const RenderArgs& a, typename X::Ctx& ctx, const BatchLds& L, const typename X::Scene& sc, unsigned long long cand,
-                          uint32_t made, uint32_t total, uint32_t npx, unsigned lane) {
+                          uint32_t made, uint32_t total, uint32_t npx, unsigned lane, uint32_t& segments) {
     using V3 = typename X::V3;
     using Best = typename X::Best;
     using Surf = typename X::Surf;
@@ -161,6 +161,7 @@ PTB uint32_t camera_batch(const RenderArgs& a, typename X::Ctx& ctx, const Batch
     const uint32_t w = made + lane;
     const uint32_t px = w & (P - 1u);
     const bool valid = w < total && px < npx;
+    segments += (uint32_t)__popcll(__ballot(valid));
     float4 ray;
     X::make_ray(a, ctx, px, (w >> lg) + (uint32_t)a.sample_begin, ray);
     const V3 o = X::v3(a.cam[0], a.cam[1], a.cam[2]), d = X::v3(ray.x, ray.y, ray.z);
@@ -237,6 +238,7 @@ PTB void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds&
     uint32_t made = 0;               // wave-uniform: pool items the batches have traced
     uint32_t parked = 0;             // wave-uniform: entries in the stash
     uint32_t qn = 0;                 // wave-uniform: entries in the queue
+    uint32_t segments = 0;           // wave-uniform: path segments traced (camera rays of the batches + ACTIVE lanes of step 4)
     const typename X::Scene sc = X::scene(a);
     for (;;) {
         // wave-uniform by construction; said once per iteration so that the compiler keeps them in scalar registers
@@ -270,7 +272,7 @@ PTB void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds&
             for (int pass = 0; pass < 2 && need != 0u; pass++) {
                 if (parked == 0u) {
                     if (made >= total) break;
-                    { const RenderArgs la = lazy_args(a); parked = camera_batch<X>(la, ctx, L, sc, cand, made, total, npx, lane); }
+                    { const RenderArgs la = lazy_args(a); parked = camera_batch<X>(la, ctx, L, sc, cand, made, total, npx, lane, segments); }
 #ifdef PT_BATCH_ONLY                 // measurement aid: camera batches alone (what they park is dropped)
                     parked = 0;
 #endif
@@ -325,6 +327,7 @@ PTB void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds&
             if (made >= total && parked == 0u && qn == 0u) break;
             continue;
         }
+        segments += (uint32_t)__popcll(__ballot(st == ACTIVE));
         // 4. one segment for every lane (a free lane steps whatever state it holds; the result is dropped)
         const Best b0 = X::scan(path.o, path.d, sc);
         X::phase(ctx, 1);
@@ -371,6 +374,7 @@ PTB void render_tile_batched(const RenderArgs& a, uint32_t tile, const BatchLds&
     }
     // p_color = totalLight / n_samples (main.cu:67); consecutive floats of consecutive pixels leave together
     const RenderArgs le = lazy_args(a);
+    ptw::add_counters(le, segments, lane);
     if (le.sums != nullptr) {
         ptw::WaveLds l; l.acc = L.acc; l.out_px = L.out_px;
         ptw::store_tile(le, l, npx, lane);

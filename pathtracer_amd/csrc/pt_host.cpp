@@ -821,7 +821,7 @@ int pt_scene_bvh_nodes(const pt_scene* sc) { return sc ? sc->n_bnodes : -1; }
 // pt_render (sums == null: all of cfg->n_samples, floats to d_fb) and pt_render_samples (samples [sample_begin,
 // sample_begin + sample_count) of them, 32.32 sums added to `sums`).
 static int render_launch(const pt_scene* sc, const pt_config* cfg, float* d_fb, int sample_begin, int sample_count,
-                         unsigned long long* sums, void* stream) {
+                         unsigned long long* sums, unsigned long long* counters, void* stream) {
     if (!sc || !cfg || (!d_fb && !sums)) return PT_FAIL("pt_render: null argument");
     if (cfg->max_x <= 0 || cfg->max_y <= 0 || cfg->n_samples <= 0 || cfg->n_bounces < 0)
         return PT_FAIL("pt_render: bad image size, n_samples or n_bounces");
@@ -859,7 +859,7 @@ static int render_launch(const pt_scene* sc, const pt_config* cfg, float* d_fb, 
     }
     a.du = du[0]; a.dv = dv[1];
     a.max_x = cfg->max_x; a.max_y = cfg->max_y;
-    a.n_samples = sample_count; a.sample_begin = sample_begin; a.sums = sums;
+    a.n_samples = sample_count; a.sample_begin = sample_begin; a.sums = sums; a.counters = counters;
     a.n_bounces = cfg->n_bounces; a.bsdf_model = cfg->bsdf_model;
     a.sample_cap = 1073741824.0f / (float)cfg->n_samples;
     a.seed_hash = host_hash(cfg->seed + 0x9E3779B9u);
@@ -959,13 +959,18 @@ extern "C" {
 
 int pt_render(const pt_scene* sc, const pt_config* cfg, float* d_fb, void* stream) {
     if (!d_fb) return PT_FAIL("pt_render: null argument");
-    return render_launch(sc, cfg, d_fb, 0, cfg ? cfg->n_samples : 0, nullptr, stream);
+    return render_launch(sc, cfg, d_fb, 0, cfg ? cfg->n_samples : 0, nullptr, nullptr, stream);
+}
+
+int pt_render_counted(const pt_scene* sc, const pt_config* cfg, float* d_fb, unsigned long long* d_counters, void* stream) {
+    if (!d_fb || !d_counters) return PT_FAIL("pt_render_counted: null argument");
+    return render_launch(sc, cfg, d_fb, 0, cfg ? cfg->n_samples : 0, nullptr, d_counters, stream);
 }
 
 int pt_render_samples(const pt_scene* sc, const pt_config* cfg, int sample_begin, int sample_count,
                       unsigned long long* d_sums, void* stream) {
     if (!d_sums) return PT_FAIL("pt_render_samples: null argument");
-    return render_launch(sc, cfg, nullptr, sample_begin, sample_count, d_sums, stream);
+    return render_launch(sc, cfg, nullptr, sample_begin, sample_count, d_sums, nullptr, stream);
 }
 
 long long pt_sums_count(const pt_config* cfg) {

@@ -196,6 +196,7 @@ struct RenderArgs {
     int32_t max_x, max_y;
     int32_t n_samples, n_bounces;   // n_samples: samples per pixel THIS launch traces, numbered sample_begin ... (RNG streams go by that number)
     int32_t sample_begin;
+    unsigned long long* counters;   // null, or where every wave adds what it traced: [0] path segments (nearest-hit searches begun)
     unsigned long long* sums;       // null: the launch writes fb = sum / n_samples; else it ADDS its pixels' 32.32 sums here (pt_render_samples)
     float sample_cap;      // 2^30 / (samples of the whole frame): what one sample's radiance counts as at most (pixel sums are 32.32 fixed point)
     int32_t bsdf_model;    // PT_BSDF_*

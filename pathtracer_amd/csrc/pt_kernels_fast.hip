@@ -1011,6 +1011,8 @@ struct FastTracer {
     static PTD bool step_path(ptf::WalkPath& p, const SceneRefs& sc, const RenderArgs& a, FastCtx& c) {
         return path_step_walk<BVH == 2>(p, sc, c.shade, c.mats, a.n_bounces, a.bsdf_model, a.walk_budget, a.shade_gate, a.leaf_gate, c.wstack, c.clk);
     }
+    static PTD bool begins_segment(const ptf::Path&) { return true; }
+    static PTD bool begins_segment(const ptf::WalkPath& p) { return p.node < 0; }
     static PTD void idle(Path& p) {
         p.o = v3(0.0f, 0.0f, 0.0f); p.d = v3(0.0f, 0.0f, 0.0f);
         p.coef = v3(0.0f, 0.0f, 0.0f); p.contrib = v3(0.0f, 0.0f, 0.0f); p.key = 0; p.seg = 0;

@@ -43,6 +43,7 @@ struct ParityTracer {
         rgb[0] = p.contrib.x; rgb[1] = p.contrib.y; rgb[2] = p.contrib.z;
     }
     static __device__ __forceinline__ void phase(ParityCtx&, int) {}
+    static __device__ __forceinline__ bool begins_segment(const Path&) { return true; }
 };
 
 __global__ __launch_bounds__(ptw::BLOCK) void render_parity_kernel(RenderArgs a, uint32_t n_tiles) {

@@ -83,6 +83,11 @@ __device__ __forceinline__ void add_sample(const WaveLds& l, uint32_t px, const 
         __hip_atomic_fetch_add(&l.acc[px * 3 + c], to_fixed(rgb[c], cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
+// What a wave traced, added to the launch's counters (pt_render_counted) by its first lane.
+__device__ __forceinline__ void add_counters(const RenderArgs& a, uint32_t segments, unsigned lane) {
+    if (a.counters != nullptr && lane == 0u) atomicAdd(&a.counters[0], (unsigned long long)segments);
+}
+
 // p_color = totalLight / n_samples (main.cu:67); consecutive floats of consecutive pixels leave together.
 // A launch that traces a range of the frame's samples adds its sums to the caller's instead (same slots, 64-bit
 // integers; atomically, so that launches on different streams may share the buffer).
@@ -121,6 +126,8 @@ __device__ __forceinline__ void store_tile(const RenderArgs& a, const WaveLds& l
 //              static void radiance(const Path&, float rgb[3]);
 //              static void phase(Ctx&, int);                          // development profiling hook, normally empty
 //              static constexpr bool STEP_IDLE_LANES;                 // step() may run for lanes without a path
+//              static bool begins_segment(const Path&);               // the next step() starts a nearest-hit search (a tracer
+//                                                                     // may spread one search over several steps)
 //              static void idle(Path&);                               // a state step() can run on harmlessly
 //
 // Handing out work lane by lane would run the camera-ray code for the lanes whose path just ended, about 27 of 64 per
@@ -147,6 +154,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, 
     uint32_t my_px = 0;
     bool active = false;
     uint32_t made = 0, taken = 0;   // wave-uniform: pool items whose ray has been made / handed out; parked = made - taken
+    uint32_t segments = 0;          // wave-uniform: path segments traced
     for (;;) {
         const unsigned long long want = __ballot(!active);
         uint32_t need = (uint32_t)__popcll(want);
@@ -176,10 +184,12 @@ __device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, 
             }
         }
         T::phase(ctx, 0);
-        if (__ballot(active) == 0ull) {
+        const unsigned long long active_m = __ballot(active);
+        if (active_m == 0ull) {
             if (taken >= total) break;
             continue;
         }
+        segments += (uint32_t)__popcll(__ballot(active && T::begins_segment(path)));
         if (T::STEP_IDLE_LANES) {
             // Lanes without a path step whatever state they hold (a finished path or the idle ray) and the result is
             // dropped: the wave spends the same time, and the path state has one definition per iteration instead of a
@@ -204,6 +214,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs& a, uint32_t tile, 
         }
         T::phase(ctx, 6);
     }
+    add_counters(a, segments, lane);
     store_tile(a, l, npx, lane);
 }
 
@@ -233,6 +244,7 @@ __device__ __forceinline__ void render_tile_blocksync(const RenderArgs& a, uint3
     uint32_t my_px = 0;
     bool active = false;
     uint32_t next = 0;   // wave-uniform
+    uint32_t segments = 0;
     for (;;) {
         const unsigned long long want = __ballot(!active);
         if (want != 0ull && next < total) {
@@ -248,8 +260,10 @@ __device__ __forceinline__ void render_tile_blocksync(const RenderArgs& a, uint3
             }
         }
         T::phase(ctx, 0);
-        const int wave_busy = (__ballot(active) != 0ull) || (next < total);
+        const unsigned long long active_m = __ballot(active);
+        const int wave_busy = (active_m != 0ull) || (next < total);
         if (!__syncthreads_or(wave_busy)) break;            // block-uniform
+        segments += (uint32_t)__popcll(active_m);
         const auto best = T::nearest_block(path, a, ctx);    // all lanes of all waves
         if (active) {
             const bool go_on = T::shade(path, best, a, ctx);
@@ -264,7 +278,7 @@ __device__ __forceinline__ void render_tile_blocksync(const RenderArgs& a, uint3
         }
         T::phase(ctx, 6);
     }
-    if (tile_valid) store_tile(a, l, npx, lane);
+    if (tile_valid) { add_counters(a, segments, lane); store_tile(a, l, npx, lane); }
 }
 
 }  // namespace ptw

@@ -127,6 +127,7 @@ int main(int argc, char** argv) {
     const size_t num_pixels = (size_t)nx * ny;
     std::vector<vec3> fb(num_pixels);
     std::vector<double> ms(n_tiles, 0.0);
+    std::vector<unsigned long long> segments((size_t)n_tiles, 0ull);
     /* --gather rccl: one row set per GPU; the tiles are all-gathered over xGMI (pt_gather_framebuffer), every GPU ends
        up with the whole frame and GPU 0's copy goes to the host.  Default: each tile is copied to the host image. */
     std::vector<pt_comm*> comms;
@@ -148,6 +149,7 @@ int main(int argc, char** argv) {
     const int tile_rows = pt_tile_rows(ny, n_tiles);
     std::vector<float*> d_gathered((size_t)n_tiles, nullptr), d_full((size_t)n_tiles, nullptr);
     std::vector<vec3*> d_tiles((size_t)n_tiles, nullptr);
+    std::vector<unsigned long long*> d_counts((size_t)n_tiles, nullptr);
     auto worker = [&](int k) {
         const int g = k % n_gpus;
         checkHipErrors(hipSetDevice(g));
@@ -168,6 +170,13 @@ int main(int argc, char** argv) {
             checkHipErrors(hipMalloc((void**)&d_full[(size_t)k], (size_t)ny * row_bytes));
         }
         d_tiles[(size_t)k] = d_fb;
+        unsigned long long* d_counters = nullptr;
+        if (stats && o.spp_chunk <= 0) {
+            checkHipErrors(hipMalloc((void**)&d_counters, PT_COUNTER_COUNT * sizeof(unsigned long long)));
+            checkHipErrors(hipMemset(d_counters, 0, PT_COUNTER_COUNT * sizeof(unsigned long long)));
+            o.d_counters = d_counters;
+            d_counts[(size_t)k] = d_counters;             // (freed with the other buffers, after every thread has joined)
+        }
         hipEvent_t e0, e1;
         checkHipErrors(hipEventCreate(&e0)); checkHipErrors(hipEventCreate(&e1));
         checkHipErrors(hipEventRecord(e0, nullptr));
@@ -178,6 +187,11 @@ int main(int argc, char** argv) {
         float t = 0.0f;
         checkHipErrors(hipEventElapsedTime(&t, e0, e1));
         ms[k] = t;
+        if (d_counters) {
+            unsigned long long c[PT_COUNTER_COUNT];
+            checkHipErrors(hipMemcpy(c, d_counters, sizeof(c), hipMemcpyDeviceToHost));
+            segments[(size_t)k] = c[PT_COUNTER_SEGMENTS];
+        }
         if (gather_rccl) {
             if (pt_gather_framebuffer(comms[(size_t)k], reinterpret_cast<const float*>(d_fb), d_gathered[(size_t)k], d_full[(size_t)k], ny, nx, nullptr) != 0) {
                 std::cerr << pt_last_error() << "\n";
@@ -197,6 +211,7 @@ int main(int argc, char** argv) {
         if (!d_tiles[(size_t)k]) continue;
         checkHipErrors(hipSetDevice(k % n_gpus));
         checkHipErrors(hipFree(d_tiles[(size_t)k]));
+        if (d_counts[(size_t)k]) checkHipErrors(hipFree(d_counts[(size_t)k]));
         if (d_gathered[(size_t)k]) checkHipErrors(hipFree(d_gathered[(size_t)k]));
         if (d_full[(size_t)k]) checkHipErrors(hipFree(d_full[(size_t)k]));
     }
@@ -206,8 +221,24 @@ int main(int argc, char** argv) {
         double worst = 0.0;
         for (double t : ms) worst = std::max(worst, t);
         const double samples = (double)num_pixels * opt.n_samples;
+        double segs = 0.0;
+        for (unsigned long long s : segments) segs += (double)s;
+        // Arithmetic per sample by the event table the benchmark prices its roofline with (add/sub/mul/min/max/div/sqrt/
+        // transcendental = 1, FMA = 2; camera ray 28; per segment a 33-flop transform + the shape's test per primitive
+        // (plane 7, sphere 21, cube 25, cylinder 49), the winner's record 53, shading 20 + a diffuse direction 23): the
+        // terms every segment has.  Glass hits and roots of hit spheres add a few per cent on the default scene.
+        double per_segment = 53.0 + 20.0 + 23.0;
+        for (int k = 0; k < n_objs; k++) {
+            const int type = scene[(size_t)k]->description().type;
+            per_segment += 33.0 + (type == PT_PLANE ? 7.0 : type == PT_SPHERE ? 21.0 : type == PT_CUBE ? 25.0 : 49.0);
+        }
+        const double flops_per_sample = segs > 0.0 ? 28.0 + per_segment * segs / samples : 0.0;
+        const double tflops = flops_per_sample * samples / (worst * 1e-3) / 1e12;
         std::clog << "{\"width\": " << nx << ", \"height\": " << ny << ", \"spp\": " << opt.n_samples << ", \"depth\": " << opt.n_bounces
-                  << ", \"gpus\": " << n_gpus << ", \"kernel_ms\": " << worst << ", \"msamples_per_s\": " << samples / worst / 1e3 << "}\n";
+                  << ", \"gpus\": " << n_gpus << ", \"samples\": " << samples << ", \"segments\": " << segs
+                  << ", \"segments_per_sample\": " << segs / samples << ", \"kernel_ms\": " << worst
+                  << ", \"msamples_per_s\": " << samples / worst / 1e3 << ", \"flops_per_sample_event_table\": " << flops_per_sample
+                  << ", \"algorithmic_tflops\": " << tflops << ", \"pct_of_fp32_vector_peak\": " << 100.0 * tflops / (157.3 * n_gpus) << "}\n";
     }
 
     if (format != "p3") {

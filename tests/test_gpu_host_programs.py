@@ -33,6 +33,11 @@ def test_host_program_matches_library_render_and_reference_ppm_format():
     assert r.returncode == 0, r.stderr.decode()
     assert b"Scanlines remaining: 64" in r.stderr           # progress line of main.cu:242
     assert b"msamples_per_s" in r.stderr
+    import json
+    stats = json.loads([l for l in r.stderr.decode().splitlines() if l.startswith("{")][-1])
+    # a segment per camera ray, at most n_bounces + 1 per sample; the default scene is closed, so every camera ray hits
+    assert stats["samples"] == 96 * 64 * 8 and 1.5 < stats["segments_per_sample"] <= 6.0
+    assert 1000.0 < stats["flops_per_sample_event_table"] < 3500.0 and 0.0 < stats["pct_of_fp32_vector_peak"] < 100.0
     # the same render through the Python binding, written by the library's P3 writer
     prims, n, mats, nm = pt.default_scene()
     img = pt.Scene(prims, n, mats, nm).render(pt.make_config(96, 64, 8, math_mode=pt.PT_MATH_PARITY)).cpu().numpy()

@@ -56,3 +56,27 @@ def test_bad_ranges_are_refused(torch, pt):
             scene.render_samples(cfg, b, n)
     with pytest.raises(pt.PtError):
         scene.render(pt.make_config(64, 36, 4, n_bounces=1 << 24))
+
+
+def test_segment_counter_is_the_same_in_every_kernel_family(torch, pt):
+    """pt_render_counted: the number of path segments (nearest-hit searches) is a property of the paths, which the
+    loops share at a seed: plain loop, loop with camera batches and LDS-staged loop count the same, the image is
+    pt_render's, and the count lies between one and n_bounces + 1 per sample.  With a hierarchy the search is spread
+    over loop iterations and still counted once per segment."""
+    from pathtracer_amd import binding as b
+    for data, depth in ((pt.default_scene(), 5), (pt.glass_grid_scene(3), 9), (pt.synthetic_scene(300, 300, 7), 4)):
+        scene = pt.Scene(*data)
+        counts = {}
+        for name, mm in (("fast", pt.PT_MATH_FAST), ("scalar", pt.PT_MATH_FAST_SCALAR), ("lds", pt.PT_MATH_FAST_LDS)):
+            cfg = pt.make_config(160, 90, 12, n_bounces=depth, math_mode=mm)
+            img, c = scene.render_counted(cfg)
+            assert torch.equal(img, scene.render(cfg)), name
+            counts[name] = int(c[0])
+        samples = 160 * 90 * 12
+        assert counts["fast"] == counts["scalar"] == counts["lds"], counts
+        assert samples <= counts["fast"] <= samples * (depth + 1)
+        cfg = pt.make_config(160, 90, 12, n_bounces=depth, math_mode=pt.PT_MATH_PARITY)
+        scene.tune(b.PT_TUNE_GLASS_QUEUE, -1)
+        plain = int(scene.render_counted(cfg)[1][0])
+        scene.tune(b.PT_TUNE_GLASS_QUEUE, 0)
+        assert int(scene.render_counted(cfg)[1][0]) == plain and samples <= plain <= samples * (depth + 1)
