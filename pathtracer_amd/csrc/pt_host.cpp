@@ -724,6 +724,9 @@ int pt_scene_upload_opt(const pt_prim* prims, int n_prims, const pt_material* ma
     UP(d_prims_by_type, dp_by_type, DPrim)
     UP(d_type_box, type_boxes, float)
     for (int t = 0; t < 5; t++) sc->type_first[t] = type_first[t];
+    sc->typed_loops_ok = 1;
+    for (const DPrim& q : dp)
+        for (int j = 0; j < 12; j++) if (!(fabsf(q.inv[j]) < 1e5f) || !(fabsf(q.fwd[j]) < 1e5f)) sc->typed_loops_ok = 0;
     UP(d_mats, dm, DMat)
     UP(d_fdata, fdata, float)
     UP(d_runs, runs, FRun)
@@ -878,7 +881,7 @@ static int render_launch(const pt_scene* sc, const pt_config* cfg, float* d_fb, 
     // (the loop with camera batches and the queue of set-aside hits shades with bsdf.h's tracePath only and searches
     // no hierarchy; the class-based model and scenes with a hierarchy keep the plain loop)
     const bool fast_batched = cfg->math_mode == PT_MATH_FAST && sc->n_bnodes == 0;
-    const bool parity_batched = cfg->math_mode == PT_MATH_PARITY && (sc->n_bnodes == 0 || sc->tune[PT_TUNE_BVH_WALK] == 3);
+    const bool parity_batched = cfg->math_mode == PT_MATH_PARITY && sc->typed_loops_ok && (sc->n_bnodes == 0 || sc->tune[PT_TUNE_BVH_WALK] == 3);
     const bool batched = (fast_batched || parity_batched) && cfg->bsdf_model == PT_BSDF_REFERENCE && sc->tune[PT_TUNE_GLASS_QUEUE] >= 0;
     a.tile_log2 = (a.n_lin >= 6000000u && !batched) ? 6 : (a.n_lin >= (batched ? 900000u : 1500000u) ? 5 : (a.n_lin >= 200000u ? 4 : 3));
     // ... and a pool of at least ~2048 samples per wave, or the drain phase dominates at low sample counts (10 000

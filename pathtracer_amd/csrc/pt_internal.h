@@ -158,6 +158,7 @@ struct pt_scene {
     DPrim* d_prims_by_type;                // the same sorted by shape type, and a world-space box for each of them
     int type_first[5];
     float* d_type_box;
+    int typed_loops_ok;                    // every entry of every T and T^-1 is below 1e5 in magnitude (see ptp::degenerate_ray)
     DMat* d_mats;
     float* d_fdata;        // fast-kernel intersection records
     FRun* d_runs;

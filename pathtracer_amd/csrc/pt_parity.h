@@ -285,9 +285,13 @@ PTD void nearest_consider_typed(Nearest& best, V3 o, V3 d, KPrimP P, int k) {
     V3 dl = xvec(P->inv, d);
     bool valid; float t; int surf = 0;
     if (TYPE == PT_PLANE) {                                                     // shapes.h:116-133
-        float dz = dl.x * 0.0f + (dl.y * 0.0f + dl.z * 1.0f);
-        V3 no = -1.0f * ol;
-        t = (no.x * 0.0f + (no.y * 0.0f + no.z * 1.0f)) / dz;
+        // The reference forms d.(0,0,1) and (-o).(0,0,1) as x*0 + (y*0 + z*1).  For finite x and y (the callers send
+        // rays with non-finite components down the scene-order loop, which keeps the literal form) the two products
+        // are zeros, so the sum is z itself whenever z != 0, and a zero of either sign when z == 0.  A zero dz fails
+        // `dz != 0` whatever its sign, and a zero numerator gives t = +-0, which `t <= 1e-5` discards whatever its
+        // sign: taking z directly changes no decision and no distance that is used.
+        float dz = dl.z;
+        t = -ol.z / dz;
         V3 pos = ol + dl * t;
         valid = (dz != 0.0f) & (P->bounds[0] < pos.x) & (P->bounds[1] < pos.y) & (P->bounds[2] > pos.x) & (P->bounds[3] > pos.y) & !(t <= 1e-5f);
     } else if (TYPE == PT_CUBE) {                                               // shapes.h:171-220
@@ -321,7 +325,13 @@ PTD void nearest_consider_typed(Nearest& best, V3 o, V3 d, KPrimP P, int k) {
             valid = second ? h.h2 : h.h1; t = second ? h.t2 : h.t1; surf = second ? h.s2 : h.s1;
         } else { valid = false; t = 0.0f; surf = 0; }
     }
-    const bool take = valid & ((best.prim < 0) | (t < best.t) | ((t == best.t) & (k < best.prim)));
+    // shapes.h:93 with the scene index deciding ties: take if no hit yet, or t < best.t, or t == best.t and k lower.
+    // Here t is a number above 1e-5 (the filter passed; the callers keep rays that could produce a NaN out of these
+    // loops), positive floats order like their bit patterns, and "no hit yet" is held as (+inf, INT_MAX): the three
+    // cases are one comparison of (t, k) pairs as 64-bit integers.
+    const unsigned long long kc = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)k;
+    const unsigned long long kb = ((unsigned long long)__float_as_uint(best.t) << 32) | (unsigned)best.prim;
+    const bool take = valid & (kc < kb);
     best.prim = take ? k : best.prim;
     best.t = take ? t : best.t;
     best.surf = take ? surf : best.surf;
@@ -329,10 +339,13 @@ PTD void nearest_consider_typed(Nearest& best, V3 o, V3 d, KPrimP P, int k) {
 
 // A ray whose distances can come out as NaN: a zero direction (refract's zero vector on total reflection,
 // vec_math.h:27, survives .normalized()) or a component that is not finite.  With a NaN in play the strict '<' of
-// shapes.h:93 depends on the order of the tests, so such rays are searched in scene order.
+// shapes.h:93 depends on the order of the tests, so such rays are searched in scene order.  The bounds are far
+// inside the float range (a direction is a unit vector or zero; origins beyond 1e5 take the scene-order loop), so
+// that with the transforms the typed loops are used for (entries below 1e5, checked at upload) every local
+// coordinate, square and discriminant is a finite number: no test of the typed loops can produce a NaN distance.
 PTD bool degenerate_ray(V3 o, V3 d) {
     const float dd = sqn(d), oo = sqn(o);
-    return !(dd > 0.0f && dd < __builtin_inff() && oo < __builtin_inff());
+    return !(dd > 0.0f && dd < 4.0f && oo < 1e10f);
 }
 
 // getNearestIntersection over the table sorted by shape type: one typed loop per type, records [first, last) of each;
@@ -346,6 +359,7 @@ PTD Nearest nearest_scan_typed(V3 o, V3 d, const PScene& S, unsigned long long m
         for (int k = 0; k < S.n_prims; k++) nearest_consider<false>(best, o, d, S.prims[k], k);
         return best;
     }
+    best.prim = 0x7fffffff; best.t = __builtin_inff();       // "no hit yet" for nearest_consider_typed
 #define PT_TYPE_LOOP(TYPE)                                                                                  \
     if (MASKED) {                                                                                            \
         const int first = S.type_first[TYPE], cnt = S.type_first[TYPE + 1] - first;                         \
@@ -364,6 +378,7 @@ PTD Nearest nearest_scan_typed(V3 o, V3 d, const PScene& S, unsigned long long m
     PT_TYPE_LOOP(PT_CYLINDER)
     PT_TYPE_LOOP(PT_SPHERE)
 #undef PT_TYPE_LOOP
+    if (best.prim == 0x7fffffff) { best.prim = -1; best.t = 0.0f; }
     return best;
 }
 
