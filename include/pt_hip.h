@@ -312,7 +312,11 @@ int pt_gather_framebuffer(pt_comm* comm, const float* d_tile, float* d_gathered,
  * PT_GATHER_NOALLOC_MAX_FLOATS (32 MiB: a 1920x1080 frame for any world <= 8);
  * larger frames are refused with an error and need pt_gather_framebuffer.
  * All calls on one GPU share that GPU's array: calls that overlap in time on
- * one GPU (different streams or communicators) race; order them. */
+ * one GPU (different streams or communicators) race; order them.
+ * Cost: the array is part of the library's code object, so its 32 MiB are
+ * resident on every GPU a process uses libpt_hip.so on, from the moment the
+ * code object is loaded there until the process ends, whether the process ever
+ * gathers or not. */
 #define PT_GATHER_NOALLOC_MAX_FLOATS (8u << 20)
 int pt_gather_framebuffer_noalloc(pt_comm* comm, const float* d_tile, float* d_full, int height, int width, void* stream);
 /* The reordering step alone: gathered[r][k] -> image row k*world + r, launched on

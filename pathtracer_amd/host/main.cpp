@@ -217,6 +217,21 @@ int main(int argc, char** argv) {
     }
     for (pt_comm* c : comms) pt_comm_free(c);
 
+    /* --gather rccl --stats: the gathered frame against the frame one GPU renders alone, byte for byte */
+    int gathered_equal = -1;
+    if (stats && gather_rccl) {
+        checkHipErrors(hipSetDevice(0));
+        render_options o = opt;
+        o.device = 0;
+        pt::DeviceScene dscene(scene.data(), n_objs, 0);
+        vec3* d_ref = nullptr;
+        checkHipErrors(hipMalloc((void**)&d_ref, num_pixels * sizeof(vec3)));
+        render(d_ref, config, dscene, o);
+        std::vector<vec3> ref(num_pixels);
+        checkHipErrors(hipMemcpy(ref.data(), d_ref, num_pixels * sizeof(vec3), hipMemcpyDeviceToHost));
+        checkHipErrors(hipFree(d_ref));
+        gathered_equal = std::memcmp(ref.data(), fb.data(), num_pixels * sizeof(vec3)) == 0 ? 1 : 0;
+    }
     if (stats) {
         double worst = 0.0;
         for (double t : ms) worst = std::max(worst, t);
@@ -238,7 +253,10 @@ int main(int argc, char** argv) {
                   << ", \"gpus\": " << n_gpus << ", \"samples\": " << samples << ", \"segments\": " << segs
                   << ", \"segments_per_sample\": " << segs / samples << ", \"kernel_ms\": " << worst
                   << ", \"msamples_per_s\": " << samples / worst / 1e3 << ", \"flops_per_sample_event_table\": " << flops_per_sample
-                  << ", \"algorithmic_tflops\": " << tflops << ", \"pct_of_fp32_vector_peak\": " << 100.0 * tflops / (157.3 * n_gpus) << "}\n";
+                  << ", \"algorithmic_tflops\": " << tflops << ", \"pct_of_fp32_vector_peak\": " << 100.0 * tflops / (157.3 * n_gpus);
+        if (gathered_equal >= 0) std::clog << ", \"gather\": \"pt_gather_framebuffer\", \"bitwise_equal_to_single_gpu\": " << (gathered_equal ? "true" : "false");
+        std::clog << "}\n";
+        if (gathered_equal == 0) { std::cerr << "the gathered frame differs from the single-GPU frame\n"; return 1; }
     }
 
     if (format != "p3") {

@@ -108,6 +108,7 @@ def test_host_program_rccl_gather_on_one_device():
     copies (one GPU here, so a communicator of one rank); same file."""
     args = ["--width", "80", "--height", "50", "--spp", "4", "--format", "pfm"]
     one = subprocess.run([_need("pathtracer")] + args, capture_output=True, timeout=120)
-    r = subprocess.run([_need("pathtracer")] + args + ["--gather", "rccl"], capture_output=True, timeout=180)
+    r = subprocess.run([_need("pathtracer")] + args + ["--gather", "rccl", "--stats"], capture_output=True, timeout=180)
+    assert b'"bitwise_equal_to_single_gpu": true' in r.stderr, r.stderr[-400:]
     assert one.returncode == 0 and r.returncode == 0, r.stderr.decode()
     assert r.stdout == one.stdout
