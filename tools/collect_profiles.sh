@@ -26,6 +26,7 @@ stats config2 python3 "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline
 stats config4_glass5_depth31 python3 "$R/tools/profile_frame.py" glass5 1920 1080 64 31 reps=8
 stats config5_10k_prims python3 "$R/tools/profile_frame.py" synthetic 1920 1080 16 5 reps=8
 stats config2_general_kinds python3 "$R/tools/profile_frame.py" default 1920 1080 64 5 general reps=8
+stats config2_parity_order python3 "$R/tools/profile_frame.py" default 1920 1080 64 5 parity reps=8
 
 cd "$R"
 step bash tools/pmc_passes.sh "$OUT/pmc_config2"
@@ -33,6 +34,7 @@ export PROG=tools/profile_frame.py
 step bash tools/pmc_passes.sh "$OUT/pmc_config4_glass5_depth31" glass5 1920 1080 64 31
 step bash tools/pmc_passes.sh "$OUT/pmc_config5_10k_prims" synthetic 1920 1080 16 5
 step bash tools/pmc_passes.sh "$OUT/pmc_config2_general_kinds" default 1920 1080 64 5 general
+step bash tools/pmc_passes.sh "$OUT/pmc_config2_parity_order" default 1920 1080 64 5 parity
 unset PROG
 
 ms_of() { python3 - "$1" <<'EOF'
@@ -44,7 +46,7 @@ for row in csv.DictReader(open(sys.argv[1])):
 print(float(best["AverageNs"]) / 1e6)
 EOF
 }
-for c in config2 config4_glass5_depth31 config5_10k_prims config2_general_kinds; do
+for c in config2 config4_glass5_depth31 config5_10k_prims config2_general_kinds config2_parity_order; do
   ms=$(ms_of "$OUT/rocprof_kernel_stats_$c.csv")
   python3 tools/pmc_summary.py "$OUT/pmc_$c" render_ "$ms" > "$OUT/pmc_$c.json" || exit 1
   for p in occupancy mix1 mix2 fetch write; do rm -rf "$OUT/pmc_$c/$p"; done
