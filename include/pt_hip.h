@@ -132,7 +132,9 @@ enum {
     PT_TUNE_WALK_BUDGET = 1, /* hierarchy nodes a lane visits (or takes off its stack) per loop iteration (>= 1) */
     PT_TUNE_SHADE_GATE = 2,  /* lanes whose hierarchy search is over before they are shaded together (1..64) */
     PT_TUNE_BVH_WALK = 3,    /* 1: PT_MATH_FAST walks the hierarchy in its skip-link form instead of the two-children-per-node
-                              * form; 3: PT_MATH_PARITY loops over all primitives although the scene has a hierarchy */
+                              * form; 2: the two-children form, but camera rays walk it like every other ray instead of being
+                              * traced in batches against their tile's own list of primitives; 3: PT_MATH_PARITY loops over
+                              * all primitives although the scene has a hierarchy */
     PT_TUNE_GLASS_QUEUE = 4, /* PT_MATH_FAST, no hierarchy: entries per wave of the LDS queue in which hits on glass
                               * wait to be shaded together (8..64); -1: no queue, every hit is shaded where it is found */
     PT_TUNE_GLASS_GATE = 5,  /* queue entries from which free lanes take them back (1..queue size) */

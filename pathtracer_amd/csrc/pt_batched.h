@@ -109,14 +109,11 @@ PTB void add_light(const BatchLds& L, uint32_t px, float r, float g, float b, fl
     __hip_atomic_fetch_add(&L.acc[px * 3u + 2u], ptw::to_fixed_in_range(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
-// Which records can a camera ray of this tile hit?  Bit s = record s of `boxes` (6 floats each: low corner, high
-// corner, padded by the uploader).  Camera rays are cam + t * (X, Y, Z0) with Z0 = p00.z - cam.z and (X, Y) inside
-// the rectangle the tile's pixels span on the sample plane (main.cu:40-63; jitter included, one pixel of margin).
-// Lane s projects box s onto that plane, clipped to the half space in front of the camera, by interval arithmetic;
-// a box whose projection misses the rectangle is dropped.  Anything undecidable (NaN from inf/inf, a box around the
-// camera) fails the "misses" compare and stays in.  Without boxes, or with more than 64 records, every bit is set.
-PTB unsigned long long tile_candidates(const RenderArgs& a, const float* boxes, int n_boxes, uint32_t lin_base, uint32_t npx, unsigned lane) {
-    if (boxes == nullptr || n_boxes > 64) return ~0ull;
+// The rectangle that the camera rays of a tile cross on the sample plane, relative to the camera: rays are
+// cam + t * (X, Y, Z0) with Z0 = p00.z - cam.z and (X, Y) inside [X0, X1] x [Y0, Y1], the span of the tile's pixels
+// (main.cu:40-63; jitter included, one pixel of margin).
+struct TileRect { float X0, X1, Y0, Y1, Z0; };
+PTB TileRect tile_rect(const RenderArgs& a, uint32_t lin_base, uint32_t npx) {
     const uint32_t W = (uint32_t)a.max_x;
     const uint32_t k0 = lin_base / W, k1 = (lin_base + npx - 1u) / W;
     const uint32_t i0 = k0 == k1 ? lin_base - k0 * W : 0u, i1 = k0 == k1 ? lin_base + npx - 1u - k0 * W : W - 1u;
@@ -126,24 +123,36 @@ PTB unsigned long long tile_candidates(const RenderArgs& a, const float* boxes, 
     const float sy0 = (float)(a.max_y - max(j0, j1)) - 1.5f, sy1 = (float)(a.max_y - min(j0, j1)) + 1.5f;
     const float xa = a.du * sx0 + (a.p00[0] - a.cam[0]), xb = a.du * sx1 + (a.p00[0] - a.cam[0]);
     const float ya = a.dv * sy0 + (a.p00[1] - a.cam[1]), yb = a.dv * sy1 + (a.p00[1] - a.cam[1]);
-    const float X0 = __builtin_fminf(xa, xb), X1 = __builtin_fmaxf(xa, xb), Y0 = __builtin_fminf(ya, yb), Y1 = __builtin_fmaxf(ya, yb);
-    const float Z0 = a.p00[2] - a.cam[2];
+    TileRect r;
+    r.X0 = __builtin_fminf(xa, xb); r.X1 = __builtin_fmaxf(xa, xb); r.Y0 = __builtin_fminf(ya, yb); r.Y1 = __builtin_fmaxf(ya, yb);
+    r.Z0 = a.p00[2] - a.cam[2];
+    return r;
+}
+// Can no camera ray of the tile pass through the box from (lx, ly, lz) to (hx, hy, hz) (relative to the camera)?  The
+// box is projected onto the sample plane, clipped to the half space in front of the camera, by interval arithmetic.
+// Anything undecidable (NaN from inf/inf, a box around the camera) fails the compares and is "not missed".
+PTB bool rect_misses_box(const TileRect& r, float lx, float ly, float lz, float hx, float hy, float hz) {
+    // ray parameter t = z / Z0 over the box; only t > 0 is in front of the camera
+    const float ta = lz / r.Z0, tb = hz / r.Z0;
+    const float t_hi = __builtin_fmaxf(ta, tb);
+    const float t_lo = __builtin_fmaxf(__builtin_fminf(ta, tb), 1e-30f);
+    const float slack = 1e-4f;
+    // projection x / t over x in [lx, hx], t in [t_lo, t_hi] (t > 0): lowest from lx, highest from hx
+    const float px_lo = __builtin_fminf(lx / t_lo, lx / t_hi), px_hi = __builtin_fmaxf(hx / t_lo, hx / t_hi);
+    const float py_lo = __builtin_fminf(ly / t_lo, ly / t_hi), py_hi = __builtin_fmaxf(hy / t_lo, hy / t_hi);
+    const float mx = slack * (__builtin_fabsf(r.X0) + __builtin_fabsf(r.X1)), my = slack * (__builtin_fabsf(r.Y0) + __builtin_fabsf(r.Y1));
+    return (t_hi <= 0.0f) || (px_hi < r.X0 - mx) || (px_lo > r.X1 + mx) || (py_hi < r.Y0 - my) || (py_lo > r.Y1 + my);
+}
+
+// Which records can a camera ray of this tile hit?  Bit s = record s of `boxes` (6 floats each: low corner, high
+// corner, padded by the uploader); lane s tests box s.  Without boxes, or with more than 64 records, every bit is set.
+PTB unsigned long long tile_candidates(const RenderArgs& a, const float* boxes, int n_boxes, uint32_t lin_base, uint32_t npx, unsigned lane) {
+    if (boxes == nullptr || n_boxes > 64) return ~0ull;
+    const TileRect r = tile_rect(a, lin_base, npx);
     bool keep = false;
     if ((int)lane < n_boxes) {
         const float* B = boxes + 6 * lane;
-        const float lx = B[0] - a.cam[0], ly = B[1] - a.cam[1], lz = B[2] - a.cam[2];
-        const float hx = B[3] - a.cam[0], hy = B[4] - a.cam[1], hz = B[5] - a.cam[2];
-        // ray parameter t = z / Z0 over the box; only t > 0 is in front of the camera
-        const float ta = lz / Z0, tb = hz / Z0;
-        const float t_hi = __builtin_fmaxf(ta, tb);
-        const float t_lo = __builtin_fmaxf(__builtin_fminf(ta, tb), 1e-30f);
-        const float slack = 1e-4f;
-        // projection x / t over x in [lx, hx], t in [t_lo, t_hi] (t > 0): lowest from lx, highest from hx
-        const float px_lo = __builtin_fminf(lx / t_lo, lx / t_hi), px_hi = __builtin_fmaxf(hx / t_lo, hx / t_hi);
-        const float py_lo = __builtin_fminf(ly / t_lo, ly / t_hi), py_hi = __builtin_fmaxf(hy / t_lo, hy / t_hi);
-        const float mx = slack * (__builtin_fabsf(X0) + __builtin_fabsf(X1)), my = slack * (__builtin_fabsf(Y0) + __builtin_fabsf(Y1));
-        const bool misses = (t_hi <= 0.0f) || (px_hi < X0 - mx) || (px_lo > X1 + mx) || (py_hi < Y0 - my) || (py_lo > Y1 + my);
-        keep = !misses;
+        keep = !rect_misses_box(r, B[0] - a.cam[0], B[1] - a.cam[1], B[2] - a.cam[2], B[3] - a.cam[0], B[4] - a.cam[1], B[5] - a.cam[2]);
     }
     return __ballot(keep);
 }

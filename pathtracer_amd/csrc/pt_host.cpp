@@ -655,6 +655,34 @@ int pt_scene_upload_opt(const pt_prim* prims, int n_prims, const pt_material* ma
         all[k] = k;
         (prims[k].type == PT_PLANE ? top : finite).push_back(k);
     }
+    // A sphere or cylinder is tested in its own frame (shapes.h:42-48), where a ray origin at distance D from a shape of
+    // scale s has coordinates of magnitude D/s: the c = |o_l|^2 - 0.25 of the quadratic (shapes.h:258-261,328-331) is
+    // then known to a few units in the last place of (D/s)^2 only, which moves the shape's apparent surface by up to
+    // about s * 2^-21 * (D/s)^2 — for a shape of scale 0.01 seen from 4 units away, a tenth of its radius.  The loop
+    // over all primitives hits that apparent surface wherever it lies; whatever culls by boxes (the hierarchy, the
+    // per-tile lists of the camera batches) must not drop such a hit, so the boxes of these shapes grow by that much,
+    // for origins anywhere in the box of the finite shapes or at the world origin (the reference's camera).  Rays from
+    // farther away than that can still see the loop and the hierarchy disagree on a grazing hit of a tiny shape.
+    {
+        float flo[3] = {0.0f, 0.0f, 0.0f}, fhi[3] = {0.0f, 0.0f, 0.0f};
+        for (int k : finite) for (int i = 0; i < 3; i++) { flo[i] = fminf(flo[i], baked[k].lo[i]); fhi[i] = fmaxf(fhi[i], baked[k].hi[i]); }
+        for (int k : finite) {
+            if (prims[k].type != PT_SPHERE && prims[k].type != PT_CYLINDER) continue;
+            const Aff fwd = aff_load(prims[k].transform);
+            float s_min = INFINITY, s_max = 0.0f, far2 = 0.0f;
+            for (int j = 0; j < 3; j++) {
+                const float c = len3(fwd.m[0][j], fwd.m[1][j], fwd.m[2][j]);
+                s_min = fminf(s_min, c); s_max = fmaxf(s_max, c);
+                const float centre = fwd.m[j][3];
+                const float away = fmaxf(fabsf(centre - flo[j]), fabsf(centre - fhi[j]));
+                far2 += away * away;
+            }
+            if (!(s_min > 0.0f) || !std::isfinite(far2)) continue;
+            const float m = sqrtf(far2) / s_min + 1.0f;
+            const float pad = fminf(s_max * 4.76837158e-7f * m * m, 0.5f * s_max);     // 2^-21; at most the shape's own radius
+            for (int i = 0; i < 3; i++) { baked[k].lo[i] -= pad; baked[k].hi[i] += pad; }
+        }
+    }
     // the parity-order kernels' table sorted by shape type, with the boxes the camera batches cull by (padded like
     // the hierarchy's boxes: the culling test's rounding must never drop a record its own test accepts)
     std::vector<DPrim> dp_by_type;
@@ -806,7 +834,7 @@ int pt_scene_tune(pt_scene* sc, int knob, int value) {
         case PT_TUNE_TILE_LOG2: ok = ok || (value >= 2 && value <= 6); break;
         case PT_TUNE_WALK_BUDGET: ok = ok || value >= 1; break;
         case PT_TUNE_SHADE_GATE: ok = ok || (value >= 1 && value <= 64); break;
-        case PT_TUNE_BVH_WALK: ok = ok || value == 1 || value == 3; break;
+        case PT_TUNE_BVH_WALK: ok = ok || value == 1 || value == 2 || value == 3; break;
         case PT_TUNE_GLASS_QUEUE: ok = ok || value == -1 || (value >= 8 && value <= 64); break;
         case PT_TUNE_GLASS_GATE: ok = ok || (value >= 1 && value <= 64); break;
         case PT_TUNE_LEAF_GATE: ok = ok || (value >= 1 && value <= 64); break;
@@ -887,7 +915,12 @@ static int render_launch(const pt_scene* sc, const pt_config* cfg, float* d_fb, 
     // ... and a pool of at least ~2048 samples per wave, or the drain phase dominates at low sample counts (10 000
     // primitives, 1080p, 4 spp: 263 ms with 32 pixels per wave, 216 ms with 64) — as long as that leaves two waves
     // for every wave slot of the chip.
-    while (a.tile_log2 < 6 && ((uint32_t)sample_count << a.tile_log2) < 2048u && (a.n_lin >> (a.tile_log2 + 1)) >= 16384u) a.tile_log2++;
+    // (the hierarchy kernel with camera batches, whose per-wave LDS grows with the tile: 512 samples — 10 000 primitives,
+    // 1080p: 4 spp 3.79 ms with 64 pixels per wave, 4.24 with 32; 16 spp 11.36 against 10.61)
+    const bool walk_cam = cfg->math_mode == PT_MATH_FAST && sc->n_bnodes > 0 && sc->d_bfat != nullptr && cfg->bsdf_model == PT_BSDF_REFERENCE &&
+                          sc->tune[PT_TUNE_BVH_WALK] != 1 && sc->tune[PT_TUNE_BVH_WALK] != 2;
+    const uint32_t pool_min = walk_cam ? 512u : 2048u;
+    while (a.tile_log2 < 6 && ((uint32_t)sample_count << a.tile_log2) < pool_min && (a.n_lin >> (a.tile_log2 + 1)) >= 16384u) a.tile_log2++;
     if (sc->tune[PT_TUNE_TILE_LOG2] != 0) a.tile_log2 = sc->tune[PT_TUNE_TILE_LOG2];
     if (cfg->tile_log2 != 0) a.tile_log2 = cfg->tile_log2;
     a.fb_layout = cfg->fb_layout;
@@ -904,11 +937,16 @@ static int render_launch(const pt_scene* sc, const pt_config* cfg, float* d_fb, 
         a.bfat = sc->d_bfat; a.walk_stack = sc->fat_depth;
         for (int k = 0; k < 3; k++) { a.fat_origin[k] = sc->fat_origin[k]; a.fat_step[k] = sc->fat_step[k]; }
         if (sc->tune[PT_TUNE_BVH_WALK] == 1) a.bfat = nullptr;
+        // camera rays in batches against each tile's own list of hierarchy primitives (bsdf.h shading only, pixels of a
+        // tile in one byte); PT_TUNE_BVH_WALK = 2 keeps the loop in which camera rays walk like every other ray
+        a.walk_cam = walk_cam;
         a.fdata = sc->d_fdata_top; a.runs = sc->d_runs_top; a.n_runs = sc->n_runs_top;
         a.sorted = sc->sorted_top;
         // measured optimum on the 10 000-primitive scene is flat around these (a visit of the fat form decides
         // about two boxes, so its budget is half the skip-link form's)
-        a.walk_budget = a.bfat ? 16 : 32; a.shade_gate = 8; a.leaf_gate = 8;
+        // (with camera batches the walkers are secondary rays only, and a later leaf phase pays: 1080p @ 64 spp 36.9 ms
+        // with a leaf gate of 8, 36.4 with 16)
+        a.walk_budget = a.bfat ? 16 : 32; a.shade_gate = 8; a.leaf_gate = walk_cam ? 16 : 8;
         if (sc->tune[PT_TUNE_LEAF_GATE] != 0) a.leaf_gate = sc->tune[PT_TUNE_LEAF_GATE];
         if (sc->tune[PT_TUNE_WALK_BUDGET] != 0) a.walk_budget = sc->tune[PT_TUNE_WALK_BUDGET];
         if (sc->tune[PT_TUNE_SHADE_GATE] != 0) a.shade_gate = sc->tune[PT_TUNE_SHADE_GATE];

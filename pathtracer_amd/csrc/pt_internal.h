@@ -227,6 +227,7 @@ struct RenderArgs {
     int32_t walk_budget;                   // hierarchy nodes a lane visits per loop iteration
     int32_t shade_gate;                    // lanes whose search is over before they are shaded together
     int32_t leaf_gate;                     // lanes holding a leaf before the wave leaves the node loop to test them
+    int32_t walk_cam;                      // 1: camera rays in batches against the tile's own list of hierarchy primitives
     // PT_MATH_FAST without a hierarchy: hits that need the full shading (glass, paths inside a shape) are set aside
     // in a per-wave queue in LDS and shaded together.  q_cap = 0: the plain loop.
     int32_t q_cap;                         // queue entries per wave (64 bytes each)

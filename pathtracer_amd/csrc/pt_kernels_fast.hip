@@ -49,7 +49,7 @@ struct PhaseClock {
 // Development aid: the phase boundaries as comments in the compiler's assembly output (tools/isa_phases.py counts the
 // instructions between them).  Not compiled into libpt_hip.so.
 struct PhaseClock { __device__ void start() {} __device__ void mark(int) {} __device__ void flush(unsigned) {} };
-#define PHASE(clk, i) asm volatile("; PHASE " #i)
+#define PHASE(clk, i) asm volatile("; PHASE %0" :: "i"(i))
 #else
 struct PhaseClock { __device__ void start() {} __device__ void mark(int) {} __device__ void flush(unsigned) {} };
 #define PHASE(clk, i) do { } while (0)
@@ -58,8 +58,10 @@ struct PhaseClock { __device__ void start() {} __device__ void mark(int) {} __de
 #ifdef PT_WALK_CENSUS
 // Development aid: where the lanes of a wave are during the hierarchy walk.  [0] trips of the node loop, then lanes
 // summed over those trips: [1] visiting a node, [2] holding a leaf, [3] finished, [4] about to pop, [5] in the wave;
-// [6] leaf phases, [7] lanes testing a leaf in them.  Not compiled into libpt_hip.so.
-__device__ unsigned long long g_walk_census[8];
+// [6] leaf phases, [7] lanes testing a leaf in them; per tile of the loop with camera batches: [8] tiles, [9] tiles whose
+// candidate list fitted, [10] candidates in those, [11] camera batches, [12] entries they parked, [13] iterations of the
+// main loop, [14] lanes with a path in them.  Not compiled into libpt_hip.so.
+__device__ unsigned long long g_walk_census[16];
 #define CENSUS(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if (__builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0u)) == 0u) atomicAdd(&g_walk_census[i], v_); } while (0)
 #else
 #define CENSUS(i, v) do { } while (0)
@@ -1166,6 +1168,283 @@ __global__ __launch_bounds__(ptw::BLOCK) void render_fast_batched_kernel(RenderA
     ctx.clk.flush(threadIdx.x & 63);
 }
 
+// ---- PT_MATH_FAST with a hierarchy: camera rays in batches against the tile's own short list of primitives -------
+//
+// The walk of the hierarchy is what a ray of unknown origin and direction needs.  The camera rays of a tile all leave
+// one point towards a few adjacent pixels: once per tile the wave descends the tree with the tile's whole view pyramid
+// (tile_hierarchy_candidates: breadth first, one node per lane, the box test of pt_batched.h's per-tile culling) and
+// keeps the primitives whose boxes the pyramid meets — a few dozen of 10 000 small shapes.  The first segment of 64
+// samples is then traced by all 64 lanes at once against the planes and that list (records through scalar loads,
+// one wave-uniform branch on the kind per record), shaded together, and what goes on is parked in LDS exactly as
+// ptb::camera_batch parks it for scenes without a hierarchy; the lanes of the main loop walk the hierarchy for
+// secondary rays only.  A tile whose list does not fit 64 entries parks its camera rays unsearched instead and
+// they walk like any other ray.  Arithmetic per path is unchanged, the (distance, index) rule does not care in which
+// order or through which path the candidates are tested, and pixel sums are order-free: same image bit for bit.
+
+struct WalkCamScene {
+    SceneRefs refs;
+    int cand;        // lane l: index into bprims of the l-th primitive of the hierarchy a camera ray of this tile can hit
+    int n_cand;      // wave-uniform
+};
+
+constexpr uint32_t STASH_CAMERA = 0x40000000u;   // a parked camera ray whose search has not begun (direction, key | -, pixel)
+
+// The primitives of the hierarchy whose boxes the tile's view pyramid meets: their indices into bprims, one per lane
+// (lane l < n: the l-th), n returned; -1 if there are more than 64 or a level of the descent is wider than 64 nodes.
+// `scratch`: 256 words of the wave's LDS.
+PTD int tile_hierarchy_candidates(const RenderArgs& a, const ptb::TileRect& rect, uint32_t* scratch, unsigned lane, int& cand) {
+    uint32_t* cur = scratch;
+    uint32_t* nxt = scratch + 64;
+    uint32_t* out = scratch + 128;
+    int n_front = 1, n_out = 0;
+    if (lane == 0) cur[0] = 0u;
+    // a node's boxes are origin + step * (sum -+ diff) per axis (BFat); relative to the camera, and widened by more than
+    // the rounding of this evaluation
+    const V3 org = v3(a.fat_origin[0] - a.cam[0], a.fat_origin[1] - a.cam[1], a.fat_origin[2] - a.cam[2]);
+    const V3 step = v3(a.fat_step[0], a.fat_step[1], a.fat_step[2]);
+    const V3 pad = v3(4e-6f * (__builtin_fabsf(a.fat_origin[0]) + __builtin_fabsf(a.cam[0]) + 65536.0f * step.x),
+                      4e-6f * (__builtin_fabsf(a.fat_origin[1]) + __builtin_fabsf(a.cam[1]) + 65536.0f * step.y),
+                      4e-6f * (__builtin_fabsf(a.fat_origin[2]) + __builtin_fabsf(a.cam[2]) + 65536.0f * step.z));
+    for (int level = 0; level < WALK_STACK_MAX + 8 && n_front > 0; level++) {
+        bool ka = false, kb = false;
+        int ra = 0, rb = 0;
+        if ((int)lane < n_front) {
+            const uint4* N = reinterpret_cast<const uint4*>(a.bfat + cur[lane]);
+            const uint4 W0 = N[0], W1 = N[1];
+#define PT_GRID_LO(w) ((float)((w) & 0xFFFFu))
+#define PT_GRID_HI(w) ((float)((w) >> 16))
+            const V3 sa = v3(PT_GRID_LO(W0.x), PT_GRID_HI(W0.x), PT_GRID_LO(W0.y)), da = v3(PT_GRID_HI(W0.y), PT_GRID_LO(W0.z), PT_GRID_HI(W0.z));
+            const V3 sb = v3(PT_GRID_LO(W0.w), PT_GRID_HI(W0.w), PT_GRID_LO(W1.x)), db = v3(PT_GRID_HI(W1.x), PT_GRID_LO(W1.y), PT_GRID_HI(W1.y));
+#undef PT_GRID_LO
+#undef PT_GRID_HI
+            const V3 la = (sa - da) * step + org - pad, ha = (sa + da) * step + org + pad;
+            const V3 lb = (sb - db) * step + org - pad, hb = (sb + db) * step + org + pad;
+            ka = !ptb::rect_misses_box(rect, la.x, la.y, la.z, ha.x, ha.y, ha.z);
+            kb = !ptb::rect_misses_box(rect, lb.x, lb.y, lb.z, hb.x, hb.y, hb.z);
+            ra = (int)W1.z; rb = (int)W1.w;
+        }
+        const unsigned long long leaf_a = __ballot(ka && ra < 0), leaf_b = __ballot(kb && rb < 0);
+        const unsigned long long in_a = __ballot(ka && ra >= 0), in_b = __ballot(kb && rb >= 0);
+        const int n_la = __popcll(leaf_a), n_lb = __popcll(leaf_b), n_ia = __popcll(in_a), n_ib = __popcll(in_b);
+        if (n_out + n_la + n_lb > 64 || n_ia + n_ib > 64) return -1;
+        if (ka && ra < 0) out[n_out + (int)ptw::prefix_count(leaf_a)] = (uint32_t)~ra;
+        if (kb && rb < 0) out[n_out + n_la + (int)ptw::prefix_count(leaf_b)] = (uint32_t)~rb;
+        if (ka && ra >= 0) nxt[(int)ptw::prefix_count(in_a)] = (uint32_t)ra;
+        if (kb && rb >= 0) nxt[n_ia + (int)ptw::prefix_count(in_b)] = (uint32_t)rb;
+        n_out += n_la + n_lb;
+        n_front = n_ia + n_ib;
+        uint32_t* t = cur; cur = nxt; nxt = t;
+    }
+    if (n_front > 0) return -1;
+    cand = (int)lane < n_out ? (int)out[lane] : 0;
+    return n_out;
+}
+
+// The fast arithmetic of a camera batch (ptb::camera_batch) for a scene with a hierarchy.
+struct FastWalkCam {
+    using V3 = ptf::V3;
+    using Path = ptf::Path;
+    using Best = ptf::Best;
+    using Surf = ptf::Surf;
+    using Ctx = FastCtx;
+    using Scene = WalkCamScene;
+    using T = FastTracer<2, true>;
+    static PTD V3 v3(float x, float y, float z) { return ptf::v3(x, y, z); }
+    static PTD void make_ray(const RenderArgs& a, Ctx& c, uint32_t px, uint32_t sample, float4& ray) { T::make_ray(a, c, px, 0u, sample, ray); }
+    static PTD Best scan_camera(V3 o, V3 d, const Scene& sc, const RenderArgs&, unsigned long long) {
+        Best b = best_none();
+        const float dd = dot(d, d), idd = rcp(dd);
+        scan_sorted<KM_PLANES>(o, d, dd, idd, sc.refs.sorted, b);          // only planes stay outside the hierarchy
+        // (1/d as walk_fat hands it to the leaves' box test)
+        const V3 inv = v3(__builtin_amdgcn_fmed3f(rcp(d.x), -1e30f, 1e30f), __builtin_amdgcn_fmed3f(rcp(d.y), -1e30f, 1e30f),
+                          __builtin_amdgcn_fmed3f(rcp(d.z), -1e30f, 1e30f));
+        for (int i = 0; i < sc.n_cand; i++) {
+            const int ref = __builtin_amdgcn_readlane(sc.cand, i);
+            const KFloatP R = as_constant(reinterpret_cast<const float*>(sc.refs.bprims + ref));
+            const int kind = __float_as_int(R[12]), id = __float_as_int(R[13]);
+            switch (kind) {
+                case FP_SPHERE_WS: test_sphere_ws(R, o, d, dd, idd, id, b); break;
+                case FP_CUBE: test_cube(R, o, d, id, b); break;
+                case FP_CUBE_AA: test_cube_box(R, o, inv, id, b); break;
+                case FP_SPHERE: test_sphere(R, o, d, id, b); break;
+                default: test_cylinder(R, o, d, id, b); break;
+            }
+        }
+        return b;
+    }
+    static PTD Surf surface(const Best& b, V3 o, V3 d, Ctx& c) { return ptf::surface(b, o, d, c.shade); }
+    static PTD void shade_emissive(Path& p, bool hit, const DMat& M) { ptf::shade_emissive(p, hit, M); }
+    static PTD bool shade_diffuse(Path& p, const Surf& s, const DMat& M, bool hit, bool keep, int n_bounces) { return ptf::shade_diffuse(p, s, M, hit, keep, n_bounces); }
+    static PTD V3 first_diffuse_coef(const DMat& M) { const V3 alb = ptf::v3(M.albedo[0], M.albedo[1], M.albedo[2]); return alb * rcp(max3(alb.x, alb.y, alb.z)); }
+};
+
+// 64 camera rays made and parked unsearched (a tile whose candidate list did not fit); returns the number parked.
+PTD uint32_t camera_batch_unsearched(const RenderArgs& a, FastCtx& ctx, const ptb::BatchLds& L, uint32_t made, uint32_t total, uint32_t npx, unsigned lane) {
+    const uint32_t lg = (uint32_t)a.tile_log2, P = 1u << lg;
+    const uint32_t w = made + lane;
+    const uint32_t px = w & (P - 1u);
+    const bool valid = w < total && px < npx;
+    float4 ray;
+    FastWalkCam::make_ray(a, ctx, px, (w >> lg) + (uint32_t)a.sample_begin, ray);
+    const unsigned long long park = __ballot(valid);
+    if (valid) {
+        const uint32_t e = ptw::prefix_count(park);
+        L.stash[e] = ray;
+        L.stash[64u + e] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(px | STASH_CAMERA));
+    }
+    return (uint32_t)__popcll(park);
+}
+
+// One tile through the wave-pool loop of pt_wavepool.h: render_tile, with the camera batches above as the source of
+// the lanes' work.
+PTD void render_tile_walkcam(const RenderArgs& a, uint32_t tile, const ptb::BatchLds& L, FastCtx& ctx) {
+    using X = FastWalkCam;
+    const unsigned lane = ptw::lane_id();
+    const uint32_t lg = (uint32_t)a.tile_log2, P = 1u << lg;
+    const uint32_t lin_base = tile << lg;
+    const uint32_t npx = min(P, a.n_lin - lin_base);
+    const uint32_t total = (uint32_t)a.n_samples << lg;
+
+    for (uint32_t k = lane; k < 3u * P; k += 64u) L.acc[k] = 0ull;
+    WalkCamScene sc;
+    sc.refs.fdata = a.fdata; sc.refs.runs = a.runs; sc.refs.n_runs = a.n_runs;
+    sc.refs.nodes = a.bnodes; sc.refs.bprims = a.bprims; sc.refs.n_nodes = a.n_bnodes; sc.refs.fat = a.bfat; sc.refs.sorted = a.sorted;
+    sc.refs.fat_origin = v3(a.fat_origin[0], a.fat_origin[1], a.fat_origin[2]); sc.refs.fat_step = v3(a.fat_step[0], a.fat_step[1], a.fat_step[2]);
+    sc.cand = 0;
+    {
+        const RenderArgs la = ptb::lazy_args(a);
+        if (lane < npx) {
+            const ptw::PixelRef ref = ptw::pixel_of(la, lin_base + lane);
+            L.out_px[lane] = ref.out;
+            X::T::prologue(la, ctx, lane, ref);
+        }
+        const ptb::TileRect rect = ptb::tile_rect(la, lin_base, npx);
+        sc.n_cand = tile_hierarchy_candidates(la, rect, reinterpret_cast<uint32_t*>(L.stash), lane, sc.cand);
+    }
+    sc.n_cand = __builtin_amdgcn_readfirstlane(sc.n_cand);
+    const bool searched = sc.n_cand >= 0;
+    CENSUS(8, 1); CENSUS(9, searched ? 1 : 0); CENSUS(10, searched ? sc.n_cand : 0);
+
+    ptf::WalkPath path;
+    X::T::idle(path);
+    uint32_t my_px = 0;
+    bool active = false;
+    uint32_t made = 0;               // wave-uniform: pool items the batches have made
+    uint32_t parked = 0;             // wave-uniform: entries in the stash
+    uint32_t segments = 0;           // wave-uniform: path segments traced
+    for (;;) {
+        made = ptb::uniform(made); parked = ptb::uniform(parked);
+        const unsigned long long want = __ballot(!active);
+        uint32_t need = (uint32_t)__popcll(want);
+        if (need != 0u) {
+            const uint32_t rank = ptw::prefix_count(want);
+            uint32_t served = 0;
+            for (int pass = 0; pass < 2 && need != 0u; pass++) {   // what is parked, then a fresh batch for the rest
+                if (parked == 0u) {
+                    if (made >= total) break;
+                    const RenderArgs la = ptb::lazy_args(a);
+                    if (searched) parked = ptb::camera_batch<X>(la, ctx, L, sc, 0ull, made, total, npx, lane, segments);
+                    else parked = camera_batch_unsearched(la, ctx, L, made, total, npx, lane);
+                    made = min(made + 64u, total);
+                    CENSUS(11, 1); CENSUS(12, parked);
+                }
+                const uint32_t take = min(need, parked);
+                if (!active && rank >= served && rank < served + take) {
+                    const uint32_t e = parked - 1u - (rank - served);
+                    const float4 A = L.stash[e], B = L.stash[64u + e];
+                    const uint32_t meta = __float_as_uint(B.w);
+                    my_px = meta & 255u;
+                    path.key = __float_as_uint(A.w);
+                    path.contrib = v3(0.0f, 0.0f, 0.0f);
+                    path.sp = 0;
+                    if (meta & (ptb::STASH_FLAG | STASH_CAMERA)) {
+                        const RenderArgs la = ptb::lazy_args(a);
+                        path.o = v3(la.cam[0], la.cam[1], la.cam[2]);
+                        path.coef = v3(1.0f, 1.0f, 1.0f);
+                        path.seg = 0;
+                        if (meta & STASH_CAMERA) {
+                            path.d = v3(A.x, A.y, A.z);
+                            path.node = -1;
+                        } else {                               // a camera ray with its hit: the search is over, the full shading is due
+                            path.d = v3(B.x, B.y, B.z);
+                            path.best.t = A.x; path.best.id = __float_as_int(A.y);
+                            path.node = WALK_NONE;
+                        }
+                    } else {
+                        // throughput after the first hit, as shade_diffuse left it
+                        path.o = v3(A.x, A.y, A.z);
+                        path.d = v3(B.x, B.y, B.z);
+                        path.coef = X::first_diffuse_coef(ctx.mats[(meta & ~(ptb::STASH_FLAG | STASH_CAMERA)) >> 8]);
+                        path.seg = 1;
+                        path.node = -1;
+                    }
+                    active = true;
+                }
+                parked -= take; served += take; need -= take;
+            }
+        }
+        if (__ballot(active) == 0ull) {
+            if (made >= total && parked == 0u) break;
+            continue;
+        }
+        segments += (uint32_t)__popcll(__ballot(active && path.node == -1));
+        CENSUS(13, 1); CENSUS(14, __popcll(__ballot(active)));
+        if (active) {
+            const bool go_on = X::T::step_path(path, sc.refs, a, ctx);
+            if (!go_on) {
+                ptb::add_light(L, my_px, path.contrib.x, path.contrib.y, path.contrib.z, a.sample_cap);
+                active = false;
+            }
+        }
+    }
+    const RenderArgs le = ptb::lazy_args(a);
+    ptw::add_counters(le, segments, lane);
+    ptw::WaveLds l; l.acc = L.acc; l.out_px = L.out_px;
+    ptw::store_tile(le, l, npx, lane);
+}
+
+// Dynamic LDS of render_fast_walkcam_kernel: the walk stacks ([waves][a.walk_stack][64] words), then per wave the parked
+// work (128 float4), the pixel sums, the pixel table and the framebuffer slots, sized by the tile.
+__host__ __device__ constexpr uint32_t walkcam_wave_bytes(uint32_t P) { return 2048u + 40u * P; }
+
+template <bool LDS_TABLES>
+__global__ __launch_bounds__(ptw::BLOCK) void render_fast_walkcam_kernel(RenderArgs a, uint32_t n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    __shared__ FShade lshade[LDS_TABLES ? LDS_MAX_PRIMS : 1];
+    __shared__ DMat lmats[LDS_TABLES ? LDS_MAX_MATS : 1];
+    FastCtx ctx;
+    if (LDS_TABLES) {
+        const uint32_t* gs = reinterpret_cast<const uint32_t*>(a.fshade);
+        uint32_t* ls = reinterpret_cast<uint32_t*>(lshade);
+        for (uint32_t w = threadIdx.x; w < (uint32_t)a.n_prims * (sizeof(FShade) / 4); w += ptw::BLOCK) ls[w] = gs[w];
+        const uint32_t* gm = reinterpret_cast<const uint32_t*>(a.mats);
+        uint32_t* lm = reinterpret_cast<uint32_t*>(lmats);
+        for (uint32_t w = threadIdx.x; w < (uint32_t)a.n_mats * (sizeof(DMat) / 4); w += ptw::BLOCK) lm[w] = gm[w];
+        __syncthreads();
+        ctx.shade = lshade; ctx.mats = lmats;
+    } else {
+        ctx.shade = a.fshade; ctx.mats = a.mats;
+    }
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * ptw::WAVES_PER_BLOCK + wave;
+    if (tile >= n_tiles) return;
+    const uint32_t P = 1u << a.tile_log2;
+    const uint32_t stack_words = (uint32_t)ptw::WAVES_PER_BLOCK * (uint32_t)a.walk_stack * 64u;
+    uint32_t* wstack = reinterpret_cast<uint32_t*>(dyn_lds);
+    unsigned char* mine = dyn_lds + 4u * stack_words + wave * walkcam_wave_bytes(P);
+    ptb::BatchLds L;
+    L.stash = reinterpret_cast<float4*>(mine);
+    L.acc = reinterpret_cast<unsigned long long*>(mine + 2048u);
+    L.pxt = reinterpret_cast<float*>(mine + 2048u + 24u * P);
+    L.out_px = reinterpret_cast<uint32_t*>(mine + 2048u + 36u * P);
+    L.gq = nullptr;
+    ctx.pxt = L.pxt; ctx.pxs = P;
+    ctx.wstack = wstack + wave * ((uint32_t)a.walk_stack * 64u) + (threadIdx.x & 63u);
+    ctx.clk.start();
+    render_tile_walkcam(a, tile, L, ctx);
+    ctx.clk.flush(threadIdx.x & 63);
+}
+
 // Dynamic LDS of render_fast_kernel: the walk stacks ([waves][a.walk_stack][64] words, fat hierarchy only), then per
 // wave the parked rays (64 float4), the pixel sums (3 x 64 bit per tile pixel), the pixel table (3 floats per tile
 // pixel) and the framebuffer slots (one word per tile pixel) — sized by the tile, so that small tiles leave room for
@@ -1306,8 +1585,8 @@ extern "C" int pt_dev_phase_cycles(unsigned long long* out, int reset) {
 #ifdef PT_WALK_CENSUS
 extern "C" int pt_dev_walk_census(unsigned long long* out, int reset) {
     PT_CHECK(hipDeviceSynchronize());
-    PT_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_census), 8 * sizeof(unsigned long long)));
-    if (reset) { unsigned long long z[8] = {0}; PT_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_walk_census), z, sizeof(z))); }
+    PT_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_census), 16 * sizeof(unsigned long long)));
+    if (reset) { unsigned long long z[16] = {0}; PT_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_walk_census), z, sizeof(z))); }
     return 0;
 }
 #endif
@@ -1331,6 +1610,11 @@ int ptk_render_fast(const RenderArgs& a, int variant, hipStream_t s) {
         if (a.bfat) {
             // the walk stacks: one column of a.walk_stack entries per lane
             const size_t stack_bytes = (size_t)ptw::WAVES_PER_BLOCK * (size_t)a.walk_stack * 64u * sizeof(uint32_t);
+            if (a.walk_cam) {
+                const size_t cam_lds = stack_bytes + (size_t)walkcam_wave_bytes(1u << a.tile_log2) * ptw::WAVES_PER_BLOCK;
+                if (tables) hipLaunchKernelGGL((render_fast_walkcam_kernel<true>), dim3(blocks), dim3(ptw::BLOCK), cam_lds, s, a, n_tiles);
+                else hipLaunchKernelGGL((render_fast_walkcam_kernel<false>), dim3(blocks), dim3(ptw::BLOCK), cam_lds, s, a, n_tiles);
+            } else
             if (tables) hipLaunchKernelGGL((render_fast_kernel<true, 2, true>), dim3(blocks), dim3(ptw::BLOCK), stack_bytes + wave_lds, s, a, n_tiles);
             else hipLaunchKernelGGL((render_fast_kernel<false, 2, true>), dim3(blocks), dim3(ptw::BLOCK), stack_bytes + wave_lds, s, a, n_tiles);
         } else {

@@ -165,7 +165,7 @@ def test_tune_rejects_bad_values(pt):
     from pathtracer_amd import binding as b
     sc = pt.Scene(*pt.default_scene())
     for knob, bad in ((b.PT_TUNE_GLASS_QUEUE, 7), (b.PT_TUNE_GLASS_QUEUE, 65), (b.PT_TUNE_GLASS_GATE, 65), (b.PT_TUNE_TILE_LOG2, 7),
-                      (b.PT_TUNE_SHADE_GATE, 65), (b.PT_TUNE_BVH_WALK, 2), (99, 1), (-1, 1)):
+                      (b.PT_TUNE_SHADE_GATE, 65), (b.PT_TUNE_BVH_WALK, 4), (99, 1), (-1, 1)):
         assert b.lib.pt_scene_tune(sc.h, knob, bad) != 0
         assert b"pt_scene_tune" in b.lib.pt_last_error()
 

@@ -154,11 +154,12 @@ def test_hierarchy_equals_loop_over_all_primitives_bitwise():
         assert torch.isfinite(a).all() and float(a.sum()) > 0.0
         assert torch.equal(a, b)
     # every way of building and walking the tree gives that image too: the split rules, leaves of several primitives
-    # (skip-link walk), the skip-link walk of one-primitive leaves
+    # (skip-link walk), the skip-link walk of one-primitive leaves, camera rays walking like every other ray (2)
+    # instead of being traced in batches against their tile's own list of primitives
     scene, (w, h, spp, depth) = cases[3]
     ref = pt.Scene(*scene).render(pt.make_config(w, h, spp, n_bounces=depth, math_mode=pt.PT_MATH_FAST_SCALAR))
     for options, walk in (({"bvh_split": pt.binding.PT_BVH_SPLIT_MEDIAN}, 0), ({"bvh_split": pt.binding.PT_BVH_SPLIT_AREA}, 0),
-                          ({"bvh_split": pt.binding.PT_BVH_SPLIT_AREA + 5}, 0), ({"bvh_leaf_prims": 4}, 0), ({}, 1)):
+                          ({"bvh_split": pt.binding.PT_BVH_SPLIT_AREA + 5}, 0), ({"bvh_leaf_prims": 4}, 0), ({}, 1), ({}, 2)):
         sc = pt.Scene(*scene, **options)
         assert sc.bvh_nodes > 0
         if walk:
@@ -194,6 +195,55 @@ def test_hierarchy_equals_loop_over_all_primitives_bitwise():
     par = sc.trace_paths(*args, seed=0, n_bounces=0, math_mode=pt.PT_MATH_PARITY).cpu().numpy()
     # one segment: the radiance is the emission of whatever the ray hits first
     assert (np.abs(fast - par).max(axis=1) > 1e-3).mean() < 0.002
+
+
+def test_camera_batches_of_hierarchy_scenes_equal_the_loop_bitwise():
+    """Scenes with a hierarchy trace their camera rays in batches against each tile's own list of primitives (found by
+    descending the tree with the tile's view pyramid); tiles whose list does not fit park their camera rays unsearched.
+    Wide frames (short lists), tiny frames (every tile sees most of the scene: no list), row subsets and tile sizes all
+    give the image of the loop over all primitives, and so does the kernel in which camera rays walk the tree."""
+    import torch
+    import pathtracer_amd as pt
+    for scene, frames in ((pt.synthetic_scene(5000, 4989, 12345), ((1920, 1080, 3, 5, 500, 520, 1), (1920, 1080, 2, 5, 3, 1080, 97), (48, 27, 16, 5, 0, 27, 1))),
+                          (pt.glass_grid_scene(10), ((1280, 720, 4, 31, 300, 330, 1), (64, 36, 8, 31, 0, 36, 1))),
+                          (pt.parse_scene(_mixed_scene_text(120)), ((1000, 562, 4, 8, 250, 290, 1), (997, 561, 2, 8, 0, 561, 40)))):
+        sc = pt.Scene(*scene)
+        walk = pt.Scene(*scene)
+        walk.tune(pt.binding.PT_TUNE_BVH_WALK, 2)
+        assert sc.bvh_nodes > 0
+        for w, h, spp, depth, r0, r1, step in frames:
+            kw = dict(n_bounces=depth, row_begin=r0, row_end=r1, row_step=step, fb_compact=1)
+            ref = sc.render(pt.make_config(w, h, spp, math_mode=pt.PT_MATH_FAST_SCALAR, **kw))
+            assert float(ref.sum()) > 0.0
+            for tile in (0, 3, 4, 5, 6):
+                a = sc.render(pt.make_config(w, h, spp, math_mode=pt.PT_MATH_FAST, tile_log2=tile, **kw))
+                assert torch.equal(a, ref), (w, h, spp, tile)
+            assert torch.equal(walk.render(pt.make_config(w, h, spp, math_mode=pt.PT_MATH_FAST, **kw)), ref), (w, h, spp)
+    # path segments are counted the same way by both loops
+    sc, walk = pt.Scene(*pt.synthetic_scene(700, 300, 7)), pt.Scene(*pt.synthetic_scene(700, 300, 7))
+    walk.tune(pt.binding.PT_TUNE_BVH_WALK, 2)
+    cfg = pt.make_config(640, 360, 4, math_mode=pt.PT_MATH_FAST)
+    (fa, ca), (fb, cb) = sc.render_counted(cfg), walk.render_counted(cfg)
+    assert torch.equal(fa, fb) and int(ca[0]) == int(cb[0]) and int(ca[0]) > 640 * 360 * 4
+
+
+def test_small_far_quadrics_hit_through_the_hierarchy_as_through_the_loop():
+    """A sphere of scale 0.01 seen from several units away is tested in a frame where the ray origin has coordinates of
+    a few hundred: its apparent surface moves by a good part of its radius with the rounding of |o_l|^2, and the loop
+    over all primitives hits it wherever it lies.  The boxes the hierarchy culls by are grown by that much at upload;
+    before, one camera sample of the 132 million of this frame (row 497) went another way than in the loop."""
+    import torch
+    import pathtracer_amd as pt
+    sc = pt.Scene(*pt.synthetic_scene(5000, 4989, 12345))
+    walk = pt.Scene(*pt.synthetic_scene(5000, 4989, 12345))
+    walk.tune(pt.binding.PT_TUNE_BVH_WALK, 2)
+    kw = dict(row_begin=490, row_end=506, fb_compact=1)
+    ref = sc.render(pt.make_config(1920, 1080, 64, math_mode=pt.PT_MATH_FAST_SCALAR, **kw))
+    assert torch.equal(sc.render(pt.make_config(1920, 1080, 64, math_mode=pt.PT_MATH_FAST, **kw)), ref)
+    assert torch.equal(walk.render(pt.make_config(1920, 1080, 64, math_mode=pt.PT_MATH_FAST, **kw)), ref)
+    par = sc.render(pt.make_config(1920, 1080, 16, math_mode=pt.PT_MATH_PARITY, **kw))
+    sc.tune(pt.binding.PT_TUNE_BVH_WALK, 3)
+    assert torch.equal(sc.render(pt.make_config(1920, 1080, 16, math_mode=pt.PT_MATH_PARITY, **kw)), par)
 
 
 def test_more_materials_and_primitives_than_the_lds_tables_hold(oracle):

@@ -18,7 +18,7 @@ for kv in sys.argv[3:]:
     assert L.pt_scene_tune(h, int(k), int(v)) == 0
 cfg = b.make_config(1920, 1080, spp)
 fb = torch.zeros((1080, 1920, 3), device="cuda")
-buf = (C.c_ulonglong * 8)()
+buf = (C.c_ulonglong * 16)()
 L.pt_dev_walk_census(buf, 1)
 assert L.pt_render(h, C.byref(cfg), C.c_void_p(fb.data_ptr()), None) == 0
 L.pt_dev_walk_census(buf, 1)
@@ -27,3 +27,7 @@ print("node-loop trips per wave-trip: lanes visiting %.1f, holding a leaf %.1f, 
       tuple(buf[i] / trips for i in (1, 2, 3, 4, 5)))
 print("trips %.0f (%.1f lane-visits per sample), leaf phases %.0f with %.1f lanes each, %.2f leaf tests per sample" %
       (trips, buf[1] / segs, buf[6], buf[7] / max(1.0, float(buf[6])), buf[7] / segs))
+if buf[8]:
+    print("loop with camera batches: %d tiles, %.1f %% with a candidate list (%.1f candidates each), %.0f camera batches parking %.1f entries each, "
+          "%.0f main-loop iterations with %.1f lanes holding a path" %
+          (buf[8], 100.0 * buf[9] / buf[8], buf[10] / max(1.0, float(buf[9])), buf[11], buf[12] / max(1.0, float(buf[11])), buf[13], buf[14] / max(1.0, float(buf[13]))))
