@@ -1,10 +1,10 @@
-"""Prints the result table of the five benchmark configurations (markdown) from profiles/r02/config_table.json and the counter passes beside it.
+"""Prints the result table of the five benchmark configurations (markdown) from profiles/r03/config_table.json and the counter passes beside it.
     python3 tools/baseline_table.py"""
 import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(ROOT, "profiles", "r02")
+P = os.path.join(ROOT, "profiles", "r03")
 rows = json.load(open(os.path.join(P, "config_table.json")))
 pmc = {"2": "pmc_config2.json", "4": "pmc_config4_glass5_depth31.json"}
 ex = {k: json.load(open(os.path.join(P, f)))["derived"]["executed_frac"] * 100 for k, f in pmc.items()}
