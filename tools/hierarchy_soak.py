@@ -25,12 +25,20 @@ for s in range(n_scenes):
     assert sc.bvh_nodes > 0
     w, h, spp, depth = int(rng.integers(40, 200)), int(rng.integers(20, 100)), int(rng.integers(1, 6)), int(rng.choice([0, 3, 5, 12, 31]))
     seed = int(rng.integers(0, 1000))
-    a = sc.render(pt.make_config(w, h, spp, n_bounces=depth, seed=seed, math_mode=pt.PT_MATH_FAST))
-    b = sc.render(pt.make_config(w, h, spp, n_bounces=depth, seed=seed, math_mode=pt.PT_MATH_FAST_SCALAR))
-    p1 = sc.render(pt.make_config(w, h, spp, n_bounces=depth, seed=seed, math_mode=pt.PT_MATH_PARITY))
+    rows = {}
+    if s % 2:
+        # a wide frame, a few of its rows: tiles narrow enough for the camera batches' per-tile lists of primitives
+        w, h = int(rng.integers(600, 2000)), int(rng.integers(400, 1100))
+        r0 = int(rng.integers(0, h - 12))
+        rows = dict(row_begin=r0, row_end=r0 + int(rng.integers(1, 12)), fb_compact=1, tile_log2=int(rng.choice([0, 3, 4, 5, 6])))
+    a = sc.render(pt.make_config(w, h, spp, n_bounces=depth, seed=seed, math_mode=pt.PT_MATH_FAST, **rows))
+    b = sc.render(pt.make_config(w, h, spp, n_bounces=depth, seed=seed, math_mode=pt.PT_MATH_FAST_SCALAR, **rows))
+    p1 = sc.render(pt.make_config(w, h, spp, n_bounces=depth, seed=seed, math_mode=pt.PT_MATH_PARITY, **rows))
     sc.tune(pt.binding.PT_TUNE_BVH_WALK, 3)
-    p2 = sc.render(pt.make_config(w, h, spp, n_bounces=depth, seed=seed, math_mode=pt.PT_MATH_PARITY))
-    ok_f, ok_p = bool(torch.equal(a, b)), bool(torch.equal(p1, p2))
+    p2 = sc.render(pt.make_config(w, h, spp, n_bounces=depth, seed=seed, math_mode=pt.PT_MATH_PARITY, **rows))
+    sc.tune(pt.binding.PT_TUNE_BVH_WALK, 2)
+    a2 = sc.render(pt.make_config(w, h, spp, n_bounces=depth, seed=seed, math_mode=pt.PT_MATH_FAST, **rows))
+    ok_f, ok_p = bool(torch.equal(a, b)) and bool(torch.equal(a2, b)), bool(torch.equal(p1, p2))
     if not (ok_f and ok_p):
         bad += 1
         print("MISMATCH scene %d: n %d walls %s opts %s frame %dx%d@%d depth %d seed %d fast %s parity %s" % (s, n, walls, opts, w, h, spp, depth, seed, ok_f, ok_p), flush=True)
