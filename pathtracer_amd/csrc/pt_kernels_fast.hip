@@ -1383,6 +1383,7 @@ PTD void render_tile_walkcam(const RenderArgs& a, uint32_t tile, const ptb::Batc
                 parked -= take; served += take; need -= take;
             }
         }
+        PHASE(ctx.clk, 0);
         if (__ballot(active) == 0ull) {
             if (made >= total && parked == 0u) break;
             continue;
@@ -1391,11 +1392,13 @@ PTD void render_tile_walkcam(const RenderArgs& a, uint32_t tile, const ptb::Batc
         CENSUS(13, 1); CENSUS(14, __popcll(__ballot(active)));
         if (active) {
             const bool go_on = X::T::step_path(path, sc.refs, a, ctx);
+            PHASE(ctx.clk, 5);
             if (!go_on) {
                 ptb::add_light(L, my_px, path.contrib.x, path.contrib.y, path.contrib.z, a.sample_cap);
                 active = false;
             }
         }
+        PHASE(ctx.clk, 6);
     }
     const RenderArgs le = ptb::lazy_args(a);
     ptw::add_counters(le, segments, lane);
