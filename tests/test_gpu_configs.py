@@ -219,6 +219,13 @@ def test_camera_batches_of_hierarchy_scenes_equal_the_loop_bitwise():
                 a = sc.render(pt.make_config(w, h, spp, math_mode=pt.PT_MATH_FAST, tile_log2=tile, **kw))
                 assert torch.equal(a, ref), (w, h, spp, tile)
             assert torch.equal(walk.render(pt.make_config(w, h, spp, math_mode=pt.PT_MATH_FAST, **kw)), ref), (w, h, spp)
+    # a camera inside the cloud of shapes (boxes around and behind the view point) and one far outside it
+    sc = pt.Scene(*pt.synthetic_scene(5000, 4989, 12345))
+    for camera in ((0.3, -0.2, -2.0), (0.0, 0.0, 6.5), (-0.95, 0.9, -1.0)):
+        kw = dict(row_begin=300, row_end=312, fb_compact=1, camera=camera)
+        ref = sc.render(pt.make_config(1920, 1080, 2, math_mode=pt.PT_MATH_FAST_SCALAR, **kw))
+        assert float(ref.sum()) > 0.0
+        assert torch.equal(sc.render(pt.make_config(1920, 1080, 2, math_mode=pt.PT_MATH_FAST, **kw)), ref), camera
     # path segments are counted the same way by both loops
     sc, walk = pt.Scene(*pt.synthetic_scene(700, 300, 7)), pt.Scene(*pt.synthetic_scene(700, 300, 7))
     walk.tune(pt.binding.PT_TUNE_BVH_WALK, 2)
