@@ -32,6 +32,7 @@
 #include <algorithm>
 #include <cstring>
 #include <limits>
+#include <string>
 #include <vector>
 
 #include "../pt_hip.h"
@@ -475,6 +476,85 @@ inline void render(vec3* fb, config_t config, const pt::DeviceScene& scene, cons
     checkHipErrors(pt_resolve(scene.handle(), &c, sums, reinterpret_cast<float*>(fb), stream));
     checkHipErrors(hipStreamSynchronize(stream));
     checkHipErrors(hipFree(sums));
+}
+
+// The sample loop with its state in a file (no counterpart in the reference, whose loop of main.cu:61-67 runs inside
+// one launch and cannot be interrupted): samples are traced in pieces of opt.spp_chunk (all at once if 0), and after
+// every piece the pixels' exact sums and the number of samples done are written to ck.path (to a temporary file that is
+// then renamed, so a kill leaves the previous state intact).  A call that finds such a file for the same frame —
+// pt_config, scene tag and buffer size all equal — goes on from it.  With ck.stop_after > 0 the call returns once at
+// least that many samples are done.  Returns the samples done: opt.n_samples when fb holds the finished image
+// (bit for bit the image of one launch, however the samples were cut); fewer when it stopped early; -1 with a message
+// on stderr when the file belongs to another frame or cannot be written.
+struct render_checkpoint {
+    std::string path;
+    unsigned long long scene_tag = 0;    // pt::scene_tag of the shapes: a state file of another scene is refused
+    int stop_after = 0;
+};
+namespace pt {
+inline unsigned long long scene_tag(Shape* const* scene, int n_objects) {
+    const SceneTables t = flatten(scene, n_objects);
+    unsigned long long h = 1469598103934665603ull;                       // FNV-1a over both tables
+    auto eat = [&](const void* p, size_t n) { const unsigned char* b = static_cast<const unsigned char*>(p); for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+    eat(t.prims.data(), t.prims.size() * sizeof(pt_prim));
+    eat(t.mats.data(), t.mats.size() * sizeof(pt_material));
+    return h;
+}
+struct CheckpointHeader {
+    char magic[8];
+    pt_config config;
+    unsigned long long scene_tag;
+    long long count;                     // 64-bit sums that follow
+    int done, pad;
+};
+}  // namespace pt
+inline int render_resumable(vec3* fb, config_t config, const pt::DeviceScene& scene, const render_options& opt, const render_checkpoint& ck,
+                            hipStream_t stream = nullptr) {
+    const pt_config c = pt_make_config(config, opt);
+    const long long n = pt_sums_count(&c);
+    if (n <= 0 || ck.path.empty()) { std::fprintf(stderr, "render_resumable: no pixels to render, or no file named\n"); return -1; }
+    pt::CheckpointHeader want;
+    std::memset(&want, 0, sizeof(want));
+    std::memcpy(want.magic, "PTSUMS1", 8);
+    want.config = c; want.scene_tag = ck.scene_tag; want.count = n;
+    std::vector<unsigned long long> host((size_t)n, 0ull);
+    int done = 0;
+    if (std::FILE* f = std::fopen(ck.path.c_str(), "rb")) {
+        pt::CheckpointHeader got;
+        const bool ok = std::fread(&got, sizeof(got), 1, f) == 1 && std::memcmp(got.magic, want.magic, 8) == 0 &&
+                        std::memcmp(&got.config, &want.config, sizeof(pt_config)) == 0 && got.scene_tag == want.scene_tag && got.count == n &&
+                        got.done >= 0 && got.done <= c.n_samples && std::fread(host.data(), sizeof(unsigned long long), (size_t)n, f) == (size_t)n;
+        std::fclose(f);
+        if (!ok) { std::fprintf(stderr, "render_resumable: %s is not the state of this frame (other size, samples, seed, rows, mode or scene), or is damaged\n", ck.path.c_str()); return -1; }
+        done = got.done;
+    }
+    unsigned long long* sums = nullptr;
+    checkHipErrors(hipSetDevice(pt_scene_device(scene.handle())));
+    checkHipErrors(hipMalloc((void**)&sums, (size_t)n * sizeof(unsigned long long)));
+    checkHipErrors(hipMemcpyAsync(sums, host.data(), (size_t)n * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+    const int chunk = opt.spp_chunk > 0 ? opt.spp_chunk : c.n_samples;
+    const std::string tmp = ck.path + ".tmp";
+    while (done < c.n_samples) {
+        const int count = std::min(chunk, c.n_samples - done);
+        checkHipErrors(pt_render_samples(scene.handle(), &c, done, count, sums, stream));
+        checkHipErrors(hipMemcpyAsync(host.data(), sums, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        checkHipErrors(hipStreamSynchronize(stream));
+        done += count;
+        want.done = done;
+        std::FILE* f = std::fopen(tmp.c_str(), "wb");
+        const bool ok = f && std::fwrite(&want, sizeof(want), 1, f) == 1 && std::fwrite(host.data(), sizeof(unsigned long long), (size_t)n, f) == (size_t)n;
+        if (f && std::fclose(f) != 0) { f = nullptr; }
+        if (!ok || !f || std::rename(tmp.c_str(), ck.path.c_str()) != 0) {
+            std::fprintf(stderr, "render_resumable: cannot write %s\n", ck.path.c_str());
+            checkHipErrors(hipFree(sums));
+            return -1;
+        }
+        if (ck.stop_after > 0 && done >= ck.stop_after && done < c.n_samples) { checkHipErrors(hipFree(sums)); return done; }
+    }
+    checkHipErrors(pt_resolve(scene.handle(), &c, sums, reinterpret_cast<float*>(fb), stream));
+    checkHipErrors(hipStreamSynchronize(stream));
+    checkHipErrors(hipFree(sums));
+    return done;
 }
 
 // The reference's launch shape: render(fb, config, scene, n_objects).

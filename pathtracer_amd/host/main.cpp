@@ -7,6 +7,9 @@
 //   --width 800 --height 800 --spp 2000 --depth 5 --seed 0 --math fast --bsdf reference|classes
 //   --scene default|glass[N]|synthetic  --scene-file FILE  --format p3|p6|pfm  --gpus 1  --stats
 //   --spp-chunk S: the sample loop as launches of at most S samples each (same image)
+//   --checkpoint FILE: the pixels' exact sums and the samples done are written to FILE after every launch (FILE.k for
+//     row set k of several); a run that finds them goes on from there.  --stop-after N ends the run (exit status 3, no
+//     image) once N samples are done, for a later run with the same flags to finish
 //   --tiles T (default = gpus): the image is split into T interleaved row sets, set k rendered on GPU k % gpus
 //   --gather host|rccl: tiles copied to the host image one by one (default), or all-gathered between the GPUs with RCCL
 // Usage, as in the reference's readme:  pathtracer > out.ppm
@@ -50,6 +53,8 @@ int main(int argc, char** argv) {
     render_options opt;                 // n_samples 2000, n_bounces 5 as in the reference
     std::string scene_name = "default", scene_file, format = "p3";
     bool stats = false, gather_rccl = false;
+    std::string checkpoint;
+    int stop_after = 0;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() -> const char* { if (i + 1 >= argc) { std::cerr << "missing value for " << a << "\n"; std::exit(2); } return argv[++i]; };
@@ -68,6 +73,8 @@ int main(int argc, char** argv) {
         else if (a == "--tiles") n_tiles = std::atoi(next());
         else if (a == "--gather") gather_rccl = std::string(next()) == "rccl";
         else if (a == "--stats") stats = true;
+        else if (a == "--checkpoint") checkpoint = next();
+        else if (a == "--stop-after") stop_after = std::atoi(next());
         else { std::cerr << "unknown flag " << a << "\n"; return 2; }
     }
     if (nx <= 0 || ny <= 0 || n_gpus < 1) { std::cerr << "bad size or gpu count\n"; return 2; }
@@ -150,6 +157,8 @@ int main(int argc, char** argv) {
     std::vector<float*> d_gathered((size_t)n_tiles, nullptr), d_full((size_t)n_tiles, nullptr);
     std::vector<vec3*> d_tiles((size_t)n_tiles, nullptr);
     std::vector<unsigned long long*> d_counts((size_t)n_tiles, nullptr);
+    std::vector<int> samples_done((size_t)n_tiles, opt.n_samples);
+    const unsigned long long tag = checkpoint.empty() ? 0ull : pt::scene_tag(scene.data(), n_objs);
     auto worker = [&](int k) {
         const int g = k % n_gpus;
         checkHipErrors(hipSetDevice(g));
@@ -171,7 +180,7 @@ int main(int argc, char** argv) {
         }
         d_tiles[(size_t)k] = d_fb;
         unsigned long long* d_counters = nullptr;
-        if (stats && o.spp_chunk <= 0) {
+        if (stats && o.spp_chunk <= 0 && checkpoint.empty()) {
             checkHipErrors(hipMalloc((void**)&d_counters, PT_COUNTER_COUNT * sizeof(unsigned long long)));
             checkHipErrors(hipMemset(d_counters, 0, PT_COUNTER_COUNT * sizeof(unsigned long long)));
             o.d_counters = d_counters;
@@ -180,7 +189,14 @@ int main(int argc, char** argv) {
         hipEvent_t e0, e1;
         checkHipErrors(hipEventCreate(&e0)); checkHipErrors(hipEventCreate(&e1));
         checkHipErrors(hipEventRecord(e0, nullptr));
-        if (my_rows > 0) render(d_fb, config, dscene, o);
+        if (my_rows > 0 && !checkpoint.empty()) {
+            render_checkpoint ck;
+            ck.path = n_tiles > 1 ? checkpoint + "." + std::to_string(k) : checkpoint;
+            ck.scene_tag = tag; ck.stop_after = stop_after;
+            samples_done[(size_t)k] = render_resumable(d_fb, config, dscene, o, ck);
+        } else if (my_rows > 0) {
+            render(d_fb, config, dscene, o);
+        }
         checkHipErrors(hipEventRecord(e1, nullptr));
         checkHipErrors(hipGetLastError());
         checkHipErrors(hipDeviceSynchronize());
@@ -216,6 +232,14 @@ int main(int argc, char** argv) {
         if (d_full[(size_t)k]) checkHipErrors(hipFree(d_full[(size_t)k]));
     }
     for (pt_comm* c : comms) pt_comm_free(c);
+    for (int done : samples_done) {
+        if (done < 0) return 2;                   // the state file belongs to another frame, or cannot be written
+        if (done < opt.n_samples) {
+            std::cerr << "stopped after " << done << " of " << opt.n_samples << " samples; the same command goes on from " << checkpoint << "\n";
+            for (Shape* s : scene) delete s;
+            return 3;
+        }
+    }
 
     /* --gather rccl --stats: the gathered frame against the frame one GPU renders alone, byte for byte */
     int gathered_equal = -1;

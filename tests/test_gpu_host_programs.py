@@ -103,6 +103,31 @@ def test_host_program_sample_loop_in_pieces():
         assert r.stdout == whole.stdout, extra
 
 
+def test_host_program_stops_and_goes_on_from_its_state_file(tmp_path):
+    """--checkpoint writes the pixels' exact sums and the samples done after every launch; --stop-after ends the run
+    early (exit status 3, no image); the same command then goes on from the file and prints the file one uninterrupted
+    launch prints, byte for byte — also with several row sets, each with its own state file.  A state file of another
+    frame is refused (exit status 2)."""
+    args = ["--width", "120", "--height", "68", "--spp", "24", "--format", "pfm"]
+    whole = subprocess.run([_need("pathtracer")] + args, capture_output=True, timeout=120)
+    assert whole.returncode == 0, whole.stderr[-400:]
+    for name, extra in (("one", []), ("tiles", ["--tiles", "3"])):
+        ck = str(tmp_path / (name + ".sums"))
+        cmd = [_need("pathtracer")] + args + extra + ["--spp-chunk", "5", "--checkpoint", ck]
+        first = subprocess.run(cmd + ["--stop-after", "9"], capture_output=True, timeout=120)
+        assert first.returncode == 3 and first.stdout == b"" and b"stopped after 10 of 24 samples" in first.stderr, first.stderr[-400:]
+        assert os.path.exists(ck + (".0" if extra else ""))
+        second = subprocess.run(cmd + ["--stop-after", "15"], capture_output=True, timeout=120)
+        assert second.returncode == 3 and b"stopped after 15 of 24 samples" in second.stderr, second.stderr[-400:]
+        last = subprocess.run(cmd, capture_output=True, timeout=120)
+        assert last.returncode == 0, last.stderr[-400:]
+        assert last.stdout == whole.stdout, name
+        again = subprocess.run(cmd, capture_output=True, timeout=120)             # a finished state: nothing left to trace
+        assert again.returncode == 0 and again.stdout == whole.stdout
+        other = subprocess.run(cmd + ["--seed", "1"], capture_output=True, timeout=120)
+        assert other.returncode == 2 and b"is not the state of this frame" in other.stderr, other.stderr[-400:]
+
+
 def test_host_program_rccl_gather_on_one_device():
     """--gather rccl: the tiles travel through pt_comm_init_all + pt_gather_framebuffer instead of per-tile host
     copies (one GPU here, so a communicator of one rank); same file."""
